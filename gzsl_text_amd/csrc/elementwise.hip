@@ -1,0 +1,435 @@
+// HBM-bound kernels of the base feature extractor: embedding gather / scatter-add, label-description average,
+// CSR neighbour mean, GRU gate math, classifier head, LDAM + BCE, AdamW, and the small backward helpers.
+// Each kernel is a grid-stride loop with lanes along the contiguous (feature) dimension, so every wave touches
+// 256 consecutive bytes per instruction; reductions go wave-shuffle -> one float atomic per wave/row.
+#include "common.h"
+#include "rng.h"
+#include "../../include/gzsl_hip.h"
+
+#define EW_THREADS 256
+static inline int ew_blocks(long long n, int per = EW_THREADS) {
+    long long b = (n + per - 1) / per;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+#define GRID_STRIDE(i, n) \
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// -------------------------------------------------------------------------------------------- embedding
+__global__ void emb_gather_kernel(const float* __restrict__ W, const int64_t* __restrict__ ids,
+                                  const float* __restrict__ mask, float* __restrict__ out, long long rows, int E,
+                                  long long row_offset, uint32_t seed, uint32_t thresh, float scale) {
+    const long long n = rows * E;
+    GRID_STRIDE(i, n) {
+        const long long row = i / E;
+        const int e = (int)(i - row * E);
+        float v = W[ids[row] * E + e];
+        if (mask) v *= mask[row];
+        if (thresh) {
+            const uint32_t u = gz_u32(gz_row_key(seed, GZSL_STREAM_EMB, (uint32_t)(row + row_offset)), (uint32_t)e);
+            v = (u >= thresh) ? v * scale : 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+__global__ void emb_scatter_kernel(float* __restrict__ dW, const int64_t* __restrict__ ids,
+                                   const float* __restrict__ mask, const float* __restrict__ dOut, long long rows, int E,
+                                   int64_t pad_idx, long long row_offset, uint32_t seed, uint32_t thresh, float scale) {
+    const long long n = rows * E;
+    GRID_STRIDE(i, n) {
+        const long long row = i / E;
+        const int e = (int)(i - row * E);
+        const int64_t id = ids[row];
+        if (id == pad_idx) continue;
+        float v = dOut[i];
+        if (mask) v *= mask[row];
+        if (thresh) {
+            const uint32_t u = gz_u32(gz_row_key(seed, GZSL_STREAM_EMB, (uint32_t)(row + row_offset)), (uint32_t)e);
+            v = (u >= thresh) ? v * scale : 0.f;
+        }
+        if (v != 0.f) atomicAdd(dW + id * E + e, v);
+    }
+}
+
+__global__ void label_avg_fwd_kernel(const float* __restrict__ W, const int64_t* __restrict__ idx,
+                                     const float* __restrict__ mask, float* __restrict__ out, int N, int Td, int E) {
+    const long long n = (long long)N * E;
+    GRID_STRIDE(i, n) {
+        const int row = (int)(i / E), e = (int)(i % E);
+        float s = 0.f, cnt = 0.f;
+        for (int j = 0; j < Td; ++j) {
+            const float mk = mask[(long long)row * Td + j];
+            cnt += mk;
+            s += mk * W[idx[(long long)row * Td + j] * E + e];
+        }
+        out[i] = s / cnt;
+    }
+}
+
+__global__ void label_avg_bwd_kernel(float* __restrict__ dW, const float* __restrict__ davg,
+                                     const int64_t* __restrict__ idx, const float* __restrict__ mask, int N, int Td,
+                                     int E, int64_t pad_idx) {
+    const long long n = (long long)N * E;
+    GRID_STRIDE(i, n) {
+        const int row = (int)(i / E), e = (int)(i % E);
+        float cnt = 0.f;
+        for (int j = 0; j < Td; ++j) cnt += mask[(long long)row * Td + j];
+        const float g = davg[i] / cnt;
+        for (int j = 0; j < Td; ++j) {
+            const int64_t id = idx[(long long)row * Td + j];
+            const float mk = mask[(long long)row * Td + j];
+            if (id != pad_idx && mk != 0.f) atomicAdd(dW + id * E + e, mk * g);
+        }
+    }
+}
+
+__global__ void spmm_csr_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                const float* __restrict__ val, const float* __restrict__ x,
+                                const float* __restrict__ pre, const float* __restrict__ post, float* __restrict__ out,
+                                int N, int H, int accumulate) {
+    const long long n = (long long)N * H;
+    GRID_STRIDE(i, n) {
+        const int row = (int)(i / H), h = (int)(i % H);
+        float s = 0.f;
+        for (int64_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+            const int64_t c = col[p];
+            float w = val[p];
+            if (pre) w *= pre[c];
+            s += w * x[c * H + h];
+        }
+        if (post) s *= post[row];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// -------------------------------------------------------------------------------------------- GRU gates
+__global__ void gru_gate_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                    const float* __restrict__ h, float* __restrict__ hn, int N, int H) {
+    const long long n = (long long)N * H;
+    GRID_STRIDE(i, n) {
+        const long long row = i / H;
+        const int c = (int)(i - row * H);
+        const float* a = gi + row * 3 * H;
+        const float* b = gh + row * 3 * H;
+        const float r = sigmoidf_(a[c] + b[c]);
+        const float z = sigmoidf_(a[H + c] + b[H + c]);
+        const float nn = tanhf(a[2 * H + c] + r * b[2 * H + c]);
+        hn[i] = (1.f - z) * nn + z * h[i];
+    }
+}
+
+__global__ void gru_gate_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ gi,
+                                    const float* __restrict__ gh, const float* __restrict__ h, float* __restrict__ dgi,
+                                    float* __restrict__ dgh, float* __restrict__ dh, int N, int H) {
+    const long long n = (long long)N * H;
+    GRID_STRIDE(i, n) {
+        const long long row = i / H;
+        const int c = (int)(i - row * H);
+        const float* a = gi + row * 3 * H;
+        const float* b = gh + row * 3 * H;
+        const float r = sigmoidf_(a[c] + b[c]);
+        const float z = sigmoidf_(a[H + c] + b[H + c]);
+        const float ghn = b[2 * H + c];
+        const float nn = tanhf(a[2 * H + c] + r * ghn);
+        const float d = dhn[i];
+        const float dn_pre = d * (1.f - z) * (1.f - nn * nn);
+        const float dz_pre = d * (h[i] - nn) * z * (1.f - z);
+        const float dr_pre = dn_pre * ghn * r * (1.f - r);
+        float* oa = dgi + row * 3 * H;
+        float* ob = dgh + row * 3 * H;
+        oa[c] = dr_pre;
+        oa[H + c] = dz_pre;
+        oa[2 * H + c] = dn_pre;
+        ob[c] = dr_pre;
+        ob[H + c] = dz_pre;
+        ob[2 * H + c] = dn_pre * r;
+        dh[i] = d * z;
+    }
+}
+
+// -------------------------------------------------------------------------------------------- classifier head
+__global__ void logits_fwd_kernel(const float* __restrict__ direct, const float* __restrict__ clf,
+                                  float* __restrict__ logits, int B, int L, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long rows = (long long)B * L;
+    long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (; row < rows; row += (long long)gridDim.x * (blockDim.x >> 6)) {
+        const int l = (int)(row % L);
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += clf[(long long)l * D + d] * fmaxf(direct[row * D + d], 0.f);
+        s = wave_sum(s);
+        if (lane == 0) logits[row] = s;
+    }
+}
+
+__global__ void logits_bwd_kernel(const float* __restrict__ direct, const float* __restrict__ clf,
+                                  const float* __restrict__ dlogits, float* __restrict__ ddirect, int B, int L, int D) {
+    const long long n = (long long)B * L * D;
+    GRID_STRIDE(i, n) {
+        const long long row = i / D;
+        const int d = (int)(i - row * D);
+        const int l = (int)(row % L);
+        ddirect[i] = direct[i] > 0.f ? dlogits[row] * clf[(long long)l * D + d] : 0.f;
+    }
+}
+
+__global__ void dclf_kernel(const float* __restrict__ direct, const float* __restrict__ dlogits,
+                            float* __restrict__ dclf, int B, int L, int D, int accumulate) {
+    const long long n = (long long)L * D;
+    GRID_STRIDE(i, n) {
+        const int l = (int)(i / D), d = (int)(i % D);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dlogits[(long long)b * L + l] * fmaxf(direct[((long long)b * L + l) * D + d], 0.f);
+        dclf[i] = accumulate ? dclf[i] + s : s;
+    }
+}
+
+__global__ void ldam_bce_kernel(const float* __restrict__ logits, const float* __restrict__ y,
+                                const float* __restrict__ margin, float C, float inv_b, float* loss,
+                                float* __restrict__ dlogits, float* __restrict__ probs, int B, int L) {
+    const long long n = (long long)B * L;
+    float part = 0.f;
+    GRID_STRIDE(i, n) {
+        const int l = (int)(i % L);
+        const float yy = y[i];
+        const float lg = logits[i];
+        float z = lg;
+        if (margin) z -= yy * margin[l] * C;
+        part += fmaxf(z, 0.f) - z * yy + log1pf(expf(-fabsf(z)));
+        if (dlogits) dlogits[i] = (1.f / (1.f + expf(-z)) - yy) * inv_b;
+        if (probs) probs[i] = 1.f / (1.f + expf(-lg));
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, part * inv_b);
+}
+
+__global__ void forward_final_kernel(const float* __restrict__ fc, const float* __restrict__ feats,
+                                     const int64_t* __restrict__ labels, const float* __restrict__ margin, float C,
+                                     float scale, float* loss, float* dfc, float* __restrict__ dfeat, int Bs, int D) {
+    const int lane = threadIdx.x & 63;
+    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (; row < Bs; row += gridDim.x * (blockDim.x >> 6)) {
+        const int64_t lab = labels[row];
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += fc[lab * D + d] * feats[(long long)row * D + d];
+        s = wave_sum(s);
+        float z = s;
+        if (margin) z -= margin[lab] * C;
+        const float dz = (1.f / (1.f + expf(-z)) - 1.f) * scale;
+        if (lane == 0 && loss) atomicAdd(loss, (fmaxf(z, 0.f) - z + log1pf(expf(-fabsf(z)))) * scale);
+        for (int d = lane; d < D; d += 64) {
+            if (dfc) atomicAdd(dfc + lab * D + d, dz * feats[(long long)row * D + d]);
+            if (dfeat) dfeat[(long long)row * D + d] = dz * fc[lab * D + d];
+        }
+    }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd) {
+    GRID_STRIDE(i, n) {
+        const float gg = g[i];
+        const float mm = m[i] * b1 + (1.f - b1) * gg;
+        const float vv = v[i] * b2 + (1.f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        float upd = mm / (sqrtf(vv) + eps);
+        if (wd > 0.f) upd += wd * p[i];
+        p[i] -= lr * upd;
+    }
+}
+
+// -------------------------------------------------------------------------------------------- helpers
+__global__ void act_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, long long n, int act) {
+    GRID_STRIDE(i, n) {
+        const float yy = y[i];
+        float f = 1.f;
+        if (act == GZSL_ACT_RELU) f = yy > 0.f ? 1.f : 0.f;
+        else if (act == GZSL_ACT_TANH) f = 1.f - yy * yy;
+        else if (act == GZSL_ACT_LRELU) f = yy > 0.f ? 1.f : 0.2f;
+        d[i] *= f;
+    }
+}
+
+// out[n] += sum_m x[m*ld + n]; block = 64 columns x 4 row-lanes, each block sweeps a row chunk
+__global__ void colsum_kernel(const float* __restrict__ x, float* out, long long M, int N, int ld, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s = 0.f;
+    if (col < N)
+        for (long long r = r0 + ry; r < r1; r += 4) s += x[r * ld + col];
+    part[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < N) atomicAdd(out + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+}
+
+__global__ void conv_pack_kernel(const float* __restrict__ W, float* __restrict__ Wp, float* __restrict__ Wflip, int F,
+                                 int E, int k) {
+    const long long n = (long long)F * E * k;
+    GRID_STRIDE(i, n) {
+        const int j = (int)(i % k);
+        const int e = (int)((i / k) % E);
+        const int f = (int)(i / ((long long)k * E));
+        const float w = W[i];
+        if (Wp) Wp[(long long)f * k * E + (long long)j * E + e] = w;
+        if (Wflip) Wflip[(long long)e * k * F + (long long)(k - 1 - j) * F + f] = w;
+    }
+}
+
+// -------------------------------------------------------------------------------------------- C ABI
+#define ST ((hipStream_t)stream)
+
+extern "C" int gzsl_emb_gather_fwd(const float* W, const int64_t* ids, const float* mask, float* out, long long rows,
+                                   int E, long long row_offset, uint32_t seed, uint32_t drop_thresh, float drop_scale,
+                                   void* stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(emb_gather_kernel, dim3(ew_blocks(rows * E)), dim3(EW_THREADS), 0, ST, W, ids, mask, out, rows, E,
+                       row_offset, seed, drop_thresh, drop_scale);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_emb_scatter_add(float* dW, const int64_t* ids, const float* mask, const float* dOut, long long rows,
+                                    int E, int64_t pad_idx, long long row_offset, uint32_t seed, uint32_t drop_thresh,
+                                    float drop_scale, void* stream) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(ew_blocks(rows * E)), dim3(EW_THREADS), 0, ST, dW, ids, mask, dOut, rows,
+                       E, pad_idx, row_offset, seed, drop_thresh, drop_scale);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_label_avg_fwd(const float* W, const int64_t* idx, const float* mask, float* out, int N, int Td,
+                                  int E, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(label_avg_fwd_kernel, dim3(ew_blocks((long long)N * E)), dim3(EW_THREADS), 0, ST, W, idx, mask, out,
+                       N, Td, E);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_label_avg_bwd(float* dW, const float* davg, const int64_t* idx, const float* mask, int N, int Td,
+                                  int E, int64_t pad_idx, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(label_avg_bwd_kernel, dim3(ew_blocks((long long)N * E)), dim3(EW_THREADS), 0, ST, dW, davg, idx,
+                       mask, N, Td, E, pad_idx);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, const float* x,
+                             const float* pre, const float* post, float* out, int N, int H, int accumulate,
+                             void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(spmm_csr_kernel, dim3(ew_blocks((long long)N * H)), dim3(EW_THREADS), 0, ST, rowptr, col, val, x,
+                       pre, post, out, N, H, accumulate);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_gru_gate_fwd(const float* gi, const float* gh, const float* h, float* hn, int N, int H,
+                                 void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(ew_blocks((long long)N * H)), dim3(EW_THREADS), 0, ST, gi, gh, h, hn, N,
+                       H);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_gru_gate_bwd(const float* dhn, const float* gi, const float* gh, const float* h, float* dgi,
+                                 float* dgh, float* dh, int N, int H, void* stream) {
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(ew_blocks((long long)N * H)), dim3(EW_THREADS), 0, ST, dhn, gi, gh, h,
+                       dgi, dgh, dh, N, H);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_logits_fwd(const float* direct, const float* clf, float* logits, int B, int L, int D,
+                               void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    hipLaunchKernelGGL(logits_fwd_kernel, dim3(ew_blocks((long long)B * L, 4)), dim3(EW_THREADS), 0, ST, direct, clf,
+                       logits, B, L, D);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_logits_bwd(const float* direct, const float* clf, const float* dlogits, float* ddirect,
+                               float* dclf, int B, int L, int D, int accumulate_dclf, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if (ddirect) {
+        hipLaunchKernelGGL(logits_bwd_kernel, dim3(ew_blocks((long long)B * L * D)), dim3(EW_THREADS), 0, ST, direct, clf,
+                           dlogits, ddirect, B, L, D);
+        GZSL_CHECK_LAUNCH();
+    }
+    if (dclf) {
+        hipLaunchKernelGGL(dclf_kernel, dim3(ew_blocks((long long)L * D)), dim3(EW_THREADS), 0, ST, direct, dlogits, dclf,
+                           B, L, D, accumulate_dclf);
+        GZSL_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int gzsl_ldam_bce(const float* logits, const float* y, const float* margin, float C, float inv_b,
+                             float* loss, float* dlogits, float* probs, int B, int L, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    int blocks = ew_blocks((long long)B * L);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ldam_bce_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST, logits, y, margin, C, inv_b, loss, dlogits,
+                       probs, B, L);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_forward_final(const float* fc, const float* feats, const int64_t* labels, const float* margin,
+                                  float C, float scale, float* loss, float* dfc, float* dfeat, int Bs, int D,
+                                  void* stream) {
+    if (Bs <= 0) return 0;
+    hipLaunchKernelGGL(forward_final_kernel, dim3(ew_blocks(Bs, 4)), dim3(EW_THREADS), 0, ST, fc, feats, labels, margin, C,
+                       scale, loss, dfc, dfeat, Bs, D);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_adamw_nobias_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                                      float beta2, float eps, float wd, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, wd);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_act_bwd(float* d, const float* y, long long n, int act, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, ST, d, y, n, act);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_colsum(const float* x, float* out, long long M, int N, int ld, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    int rows_per_block = 256;
+    long long gy = (M + rows_per_block - 1) / rows_per_block;
+    if (gy > 4096) {
+        rows_per_block = (int)((M + 4095) / 4096);
+        gy = (M + rows_per_block - 1) / rows_per_block;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), (unsigned)gy), dim3(256), 0, ST, x, out, M, N, ld,
+                       rows_per_block);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_conv_weight_pack(const float* W, float* Wp, float* Wflip, int F, int E, int k, void* stream) {
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(ew_blocks((long long)F * E * k)), dim3(EW_THREADS), 0, ST, W, Wp, Wflip, F,
+                       E, k);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" const char* gzsl_build_info(void) { return "libgzsl_hip gfx950 (MI355X) fp32-mfma16x16x4"; }

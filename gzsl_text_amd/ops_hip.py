@@ -1,0 +1,317 @@
+"""Tensor-level operations of the hot path, each one or two launches of libgzsl_hip.so.
+
+`HipOps` is the only kernel provider the product uses.  The engine (engine.py, gan_engine.py,
+parallel.py) is written against this interface so that its orchestration -- not its arithmetic --
+can also be exercised on CPU by the test suite's stand-in (tests/ops_cpu.py).  Nothing here falls
+back to torch arithmetic: torch supplies device memory (empty/zeros), views and streams only.
+"""
+import torch
+
+from . import hip
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, GzslGemm, call, ptr  # noqa: F401
+
+INT_MAX = 2 ** 31 - 1
+
+
+def drop_params(p):
+    """(threshold, keep scale) of the counter RNG for drop probability p (threshold computed in double)."""
+    if p is None or p <= 0.0:
+        return 0, 1.0
+    return min(int(float(p) * 4294967296.0), 0xFFFFFFFF), 1.0 / (1.0 - float(p))
+
+
+def _check_f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f'expected float32 tensor, got {t.dtype}')
+
+
+class HipOps:
+    name = 'hip'
+
+    # ------------------------------------------------------------------------------------ GEMM plumbing
+    @staticmethod
+    def _split_policy(M, N, K):
+        """Split K when the output has too few tiles to fill 256 CUs (weight gradients: small MxN, huge K)."""
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if tiles >= 128 or K < 2048:
+            return 1, 0
+        split = min(max(1, 512 // tiles), max(1, K // 512))
+        if split <= 1:
+            return 1, 0
+        kper = ((K + split - 1) // split + 31) // 32 * 32
+        split = (K + kper - 1) // kper
+        return split, kper
+
+    def _launch(self, g, M, N, K, out, bias, act, accumulate, split, kper, unpack=None):
+        g.M, g.N, g.K = M, N, K
+        g.alpha = g.alpha if g.alpha else 1.0
+        if split > 1 or unpack is not None:
+            if split <= 1:
+                # one real slab: blockIdx.z = 1 gets an empty K range and stores zeros, the reduce kernel then
+                # applies the unpack / accumulate / epilogue exactly as for a real split
+                split, kper = 2, max(32, (K + 31) // 32 * 32)
+            slab = torch.empty((split, M, N), dtype=torch.float32, device=out.device)
+            g.C, g.ldc, g.bias, g.act, g.accumulate = slab.data_ptr(), N, None, ACT_NONE, 0
+            g.split_k, g.k_per_split, g.slab_stride = split, kper, M * N
+            call('gzsl_gemm', g)
+            uk, ue = unpack if unpack is not None else (0, 0)
+            ldo = out.stride(0) if (unpack is None and out.dim() == 2) else N
+            call('gzsl_splitk_reduce', slab.data_ptr(), M * N, split, out.data_ptr(), M, N, ldo,
+                 ptr(bias), act, int(accumulate), uk, ue)
+        else:
+            g.C, g.ldc = out.data_ptr(), out.stride(0)
+            g.bias, g.act, g.accumulate = ptr(bias), act, int(accumulate)
+            g.split_k, g.k_per_split, g.slab_stride = 1, 0, 0
+            call('gzsl_gemm', g)
+        return out
+
+    def mm(self, A, B, out=None, bias=None, act=ACT_NONE, accumulate=False, alpha=1.0, allow_split=True):
+        """out[M,N] = act(alpha * A @ B + bias (+ out)); A, B arbitrary-strided 2-D views, out row-major rows."""
+        _check_f32(A, B, out, bias)
+        M, K = A.shape
+        K2, N = B.shape
+        assert K == K2, (A.shape, B.shape)
+        if out is None:
+            assert not accumulate
+            out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        assert out.shape == (M, N) and out.stride(1) == 1
+        if not A.is_cuda:
+            raise RuntimeError('gzsl_text_amd kernels need tensors on a HIP device; there is no CPU path')
+        g = GzslGemm()
+        g.A, g.B = A.data_ptr(), B.data_ptr()
+        g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span = max(M, 1), 0, A.stride(0), A.stride(1), 0, INT_MAX
+        g.k_inner, g.a_kbs, g.b_kbs = max(K, 1), 0, 0
+        g.b_sk, g.b_sn = B.stride(0), B.stride(1)
+        g.alpha = alpha
+        split, kper = self._split_policy(M, N, K) if allow_split else (1, 0)
+        return self._launch(g, M, N, K, out, bias, act, accumulate, split, kper)
+
+    def linear(self, x, W, b=None, act=ACT_NONE, out=None, accumulate=False):
+        """nn.Linear: x[M,K] @ W[N,K]^T + b."""
+        return self.mm(x, W.t(), out=out, bias=b, act=act, accumulate=accumulate)
+
+    def colsum(self, x2d, out=None):
+        M, N = x2d.shape
+        assert x2d.stride(1) == 1
+        if out is None:
+            out = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+        call('gzsl_colsum', x2d.data_ptr(), ptr(out), M, N, x2d.stride(0))
+        return out
+
+    def act_bwd_(self, d, y, act):
+        call('gzsl_act_bwd', ptr(d), ptr(y), d.numel(), act)
+        return d
+
+    # ------------------------------------------------------------------------------------ embedding + conv encoder
+    def emb_gather(self, W, ids, mask, seed, p, row_offset=0):
+        rows = ids.numel()
+        E = W.shape[1]
+        out = torch.empty(tuple(ids.shape) + (E,), dtype=torch.float32, device=W.device)
+        th, sc = drop_params(p)
+        call('gzsl_emb_gather_fwd', ptr(W), ptr(ids), ptr(mask), ptr(out), rows, E, row_offset, seed & 0xFFFFFFFF, th, sc)
+        return out
+
+    def emb_scatter_add_(self, dW, ids, mask, dOut, seed, p, pad_idx=0, row_offset=0):
+        th, sc = drop_params(p)
+        call('gzsl_emb_scatter_add', ptr(dW), ptr(ids), ptr(mask), ptr(dOut), ids.numel(), dW.shape[1], pad_idx,
+             row_offset, seed & 0xFFFFFFFF, th, sc)
+        return dW
+
+    def conv_relu(self, e, Wc, bc):
+        """relu(conv1d(e^T, Wc) + bc)^T: e [B,T,E], Wc [F,E,k] -> X [B,T',F] (icd_modules.py:131-132)."""
+        B, T, E = e.shape
+        F_, _, k = Wc.shape
+        Tp = T - k + 1
+        Wp = torch.empty((F_, k * E), dtype=torch.float32, device=e.device)
+        call('gzsl_conv_weight_pack', ptr(Wc), ptr(Wp), None, F_, E, k)
+        X = torch.empty((B, Tp, F_), dtype=torch.float32, device=e.device)
+        g = GzslGemm()
+        g.A, g.B = e.data_ptr(), Wp.data_ptr()
+        g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span = Tp, T * E, E, 1, 0, INT_MAX
+        g.k_inner, g.a_kbs, g.b_kbs = k * E, 0, 0
+        g.b_sk, g.b_sn = 1, k * E
+        g.alpha = 1.0
+        self._launch(g, B * Tp, F_, k * E, X.view(B * Tp, F_), bc, ACT_RELU, False, 1, 0)
+        return X
+
+    def conv_bwd(self, dY, e, Wc, need_de=True):
+        """dY [B,T',F] (already multiplied by the relu mask) -> (de [B,T,E] | None, dWc [F,E,k], dbc [F])."""
+        B, T, E = e.shape
+        F_, _, k = Wc.shape
+        Tp = T - k + 1
+        dev = e.device
+        dY2 = dY.view(B * Tp, F_)
+        dbc = self.colsum(dY2)
+        # weight gradient, computed transposed ([k*E, F]) so that N = F uses the 208-wide tile
+        dWc = torch.empty((F_, E, k), dtype=torch.float32, device=dev)
+        g = GzslGemm()
+        g.A, g.B = e.data_ptr(), dY.data_ptr()
+        M, N, K = k * E, F_, B * Tp
+        g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span = M, 0, 1, E, 0, INT_MAX
+        g.k_inner, g.a_kbs = Tp, T * E
+        g.b_sk, g.b_sn, g.b_kbs = F_, 1, Tp * F_
+        g.alpha = 1.0
+        if Tp < 32:  # the in-kernel k decomposition needs k_inner >= 32: tiny notes go one note at a time
+            dWc.zero_()
+            for b in range(B):
+                g2 = GzslGemm()
+                g2.A, g2.B = e[b].data_ptr(), dY[b].data_ptr()
+                g2.a_mb, g2.a_mbs, g2.a_sm, g2.a_sk, g2.a_shift, g2.a_span = M, 0, 1, E, 0, INT_MAX
+                g2.k_inner, g2.a_kbs, g2.b_sk, g2.b_sn, g2.b_kbs, g2.alpha = Tp, 0, F_, 1, 0, 1.0
+                self._launch(g2, M, N, Tp, dWc, None, ACT_NONE, True, 1, 0, unpack=(k, E))
+        else:
+            split, kper = self._split_policy(M, N, K)
+            self._launch(g, M, N, K, dWc, None, ACT_NONE, False, split, kper, unpack=(k, E))
+        de = None
+        if need_de:
+            Wflip = torch.empty((E, k * F_), dtype=torch.float32, device=dev)
+            call('gzsl_conv_weight_pack', ptr(Wc), None, ptr(Wflip), F_, E, k)
+            de = torch.empty((B, T, E), dtype=torch.float32, device=dev)
+            g = GzslGemm()
+            g.A, g.B = dY.data_ptr(), Wflip.data_ptr()
+            g.a_mb, g.a_mbs, g.a_sm, g.a_sk = T, Tp * F_, F_, 1
+            g.a_shift, g.a_span = -(k - 1) * F_, Tp * F_
+            g.k_inner, g.a_kbs, g.b_kbs = k * F_, 0, 0
+            g.b_sk, g.b_sn = 1, k * F_
+            g.alpha = 1.0
+            self._launch(g, B * T, E, k * F_, de.view(B * T, E), None, ACT_NONE, False, 1, 0)
+        return de, dWc, dbc
+
+    # ------------------------------------------------------------------------------------ label side
+    def label_avg(self, W, idx, mask):
+        N, Td = idx.shape
+        out = torch.empty((N, W.shape[1]), dtype=torch.float32, device=W.device)
+        call('gzsl_label_avg_fwd', ptr(W), ptr(idx), ptr(mask), ptr(out), N, Td, W.shape[1])
+        return out
+
+    def label_avg_bwd_(self, dW, davg, idx, mask, pad_idx=0):
+        N, Td = idx.shape
+        call('gzsl_label_avg_bwd', ptr(dW), ptr(davg), ptr(idx), ptr(mask), N, Td, dW.shape[1], pad_idx)
+        return dW
+
+    def spmm(self, csr, x, pre=None, post=None, out=None, accumulate=False):
+        rowptr, col, val = csr
+        N, H = x.shape
+        if out is None:
+            assert not accumulate
+            out = torch.empty((N, H), dtype=torch.float32, device=x.device)
+        call('gzsl_spmm_csr', ptr(rowptr), ptr(col), ptr(val), ptr(x), ptr(pre), ptr(post), ptr(out), N, H,
+             int(accumulate))
+        return out
+
+    def gru_gate_fwd(self, gi, gh, h):
+        hn = torch.empty_like(h)
+        call('gzsl_gru_gate_fwd', ptr(gi), ptr(gh), ptr(h), ptr(hn), h.shape[0], h.shape[1])
+        return hn
+
+    def gru_gate_bwd(self, dhn, gi, gh, h):
+        dgi, dgh, dh = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        call('gzsl_gru_gate_bwd', ptr(dhn), ptr(gi), ptr(gh), ptr(h), ptr(dgi), ptr(dgh), ptr(dh), h.shape[0],
+             h.shape[1])
+        return dgi, dgh, dh
+
+    # ------------------------------------------------------------------------------------ attention + head + loss
+    def attn_fwd(self, PX, X, Q, l_offset, L_total, seed, p):
+        B, Tp, E = PX.shape
+        F_ = X.shape[2]
+        L = Q.shape[0]
+        O = torch.empty((B, L, F_), dtype=torch.float32, device=PX.device)
+        lse = torch.empty((B, L), dtype=torch.float32, device=PX.device)
+        th, sc = drop_params(p)
+        call('gzsl_label_attn_fwd', ptr(PX), ptr(X), ptr(Q), ptr(O), ptr(lse), B, Tp, E, F_, L, l_offset, L_total,
+             seed & 0xFFFFFFFF, th, sc)
+        return O, lse
+
+    def attn_bwd(self, dO, O, PX, X, Q, lse, l_offset, L_total, seed, p, dPX, dX, dQ, nsplit=None):
+        """Accumulates into dPX [B,Tp,E], dX [B,Tp,F], dQ [L,E]."""
+        B, Tp, E = PX.shape
+        F_ = X.shape[2]
+        L = Q.shape[0]
+        delta = torch.empty((B, L), dtype=torch.float32, device=PX.device)
+        call('gzsl_attn_delta', ptr(dO), ptr(O), ptr(delta), B * L, F_)
+        if nsplit is None:
+            tok_per_wg = 128 if E <= 100 else 64
+            wgs = B * ((Tp + tok_per_wg - 1) // tok_per_wg)
+            nsplit = 1
+            while wgs * nsplit < 1024 and nsplit * 2 * 16 <= L:
+                nsplit *= 2
+        th, sc = drop_params(p)
+        call('gzsl_label_attn_bwd', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
+             ptr(dQ), B, Tp, E, F_, L, l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc)
+
+    def logits_fwd(self, direct, clf):
+        B, L, D = direct.shape
+        logits = torch.empty((B, L), dtype=torch.float32, device=direct.device)
+        call('gzsl_logits_fwd', ptr(direct), ptr(clf), ptr(logits), B, L, D)
+        return logits
+
+    def logits_bwd(self, direct, clf, dlogits, need_ddirect=True):
+        B, L, D = direct.shape
+        ddirect = torch.empty_like(direct) if need_ddirect else None
+        dclf = torch.empty((L, D), dtype=torch.float32, device=direct.device)
+        call('gzsl_logits_bwd', ptr(direct), ptr(clf), ptr(dlogits), ptr(ddirect), ptr(dclf), B, L, D, 0)
+        return ddirect, dclf
+
+    def ldam_bce(self, logits, y, margin, C, inv_b, need_grad=True, need_probs=False):
+        B, L = logits.shape
+        loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits) if need_grad else None
+        probs = torch.empty_like(logits) if need_probs else None
+        use_margin = margin is not None and C > 0
+        call('gzsl_ldam_bce', ptr(logits), ptr(y), ptr(margin) if use_margin else None, float(C), float(inv_b),
+             ptr(loss), ptr(dlogits), ptr(probs), B, L)
+        return loss, dlogits, probs
+
+    def forward_final(self, fc, feats, labels, margin, C, scale, need_grad=True):
+        Bs, D = feats.shape
+        loss = torch.zeros((), dtype=torch.float32, device=feats.device)
+        dfc = torch.zeros_like(fc) if need_grad else None
+        use_margin = margin is not None and C > 0
+        call('gzsl_forward_final', ptr(fc), ptr(feats), ptr(labels), ptr(margin) if use_margin else None, float(C),
+             float(scale), ptr(loss), ptr(dfc), None, Bs, D)
+        return loss, dfc
+
+    def adamw_step_(self, p, g, m, v, lr, beta1, beta2, eps, wd):
+        call('gzsl_adamw_nobias_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, wd)
+
+    # ------------------------------------------------------------------------------------ WGAN-GP pieces
+    def gp_interp(self, real, fake, alpha):
+        out = torch.empty_like(real)
+        call('gzsl_gp_interp', ptr(real), ptr(fake), ptr(alpha), ptr(out), real.shape[0], real.shape[1])
+        return out
+
+    def gp_slope_v(self, h, w2):
+        v, s = torch.empty_like(h), torch.empty_like(h)
+        call('gzsl_gp_slope_v', ptr(h), ptr(w2), ptr(v), ptr(s), h.shape[0], h.shape[1])
+        return v, s
+
+    def gp_rownorm_(self, g, lam):
+        gp = torch.zeros((), dtype=torch.float32, device=g.device)
+        call('gzsl_gp_rownorm', ptr(g), ptr(gp), g.shape[0], g.shape[1], float(lam))
+        return gp
+
+    def gp_dw2_(self, dv, s, dw2):
+        call('gzsl_gp_dw2', ptr(dv), ptr(s), ptr(dw2), dv.shape[0], dv.shape[1])
+
+    def rowdot(self, a, w, bias):
+        out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
+        call('gzsl_rowdot', ptr(a), ptr(w), ptr(bias), ptr(out), a.shape[0], a.shape[1])
+        return out
+
+    def weighted_sum(self, x, w, scale):
+        out = torch.zeros((), dtype=torch.float32, device=x.device)
+        call('gzsl_weighted_sum', ptr(x), ptr(w), float(scale), ptr(out), x.numel())
+        return out
+
+    def rowdot_bwd(self, dout, w, act, dw, db, need_da=True):
+        da = torch.empty_like(act) if need_da else None
+        call('gzsl_rowdot_bwd', ptr(dout), ptr(w), ptr(act), ptr(da), ptr(dw), ptr(db), act.shape[0], act.shape[1])
+        return da
+
+    def keyword_ce_(self, logits, kw_idx, kw_mask, w):
+        """Returns per-row loss; overwrites `logits` with w_b * d loss_b / d logits."""
+        Bg, Vk = logits.shape
+        loss_b = torch.empty(Bg, dtype=torch.float32, device=logits.device)
+        call('gzsl_keyword_ce', ptr(logits), ptr(kw_idx), ptr(kw_mask), ptr(w), ptr(loss_b), Bg, Vk, kw_idx.shape[1])
+        return loss_b

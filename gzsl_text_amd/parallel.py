@@ -1,0 +1,98 @@
+"""Label-dimension sharding of the base model over one process per GPU (RCCL through torch.distributed).
+
+The reference is single-device; this is what the build adds (8e).  Labels are independent given the
+encoder output (softmax is over tokens, not labels), so rank r owns a contiguous range of the attention query rows
+(average label embedding), classifier rows (graph label embedding / output_fc), margins and y columns:
+
+  forward   each rank encodes B/P notes ............. all_gather  X||PX      [B,T',F+E]   (mesh over xGMI)
+            fused attention + head on its L/P labels
+            logits shards ........................... all_gather  logits     [B,L]
+            loss partial sums ....................... all_reduce  1 float
+  backward  partial dX||dPX from each label shard ... reduce_scatter over the batch
+            each rank backprops its B/P notes; label-side gradients are backpropagated from the rank's zero-padded
+            d(avg)/d(graph) through its replica (the encoders are linear in the incoming gradient)
+            every shared-parameter gradient ......... all_reduce  one flat bucket
+
+When B is not divisible by P the encoder is replicated instead (every rank encodes all notes; dX is all-reduced).
+All ranks must hold identical parameters, draw the same batch and use the same dropout seed; the dropout hash is
+keyed on global (note, label, token) coordinates, so results do not depend on P.
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition(n, world, rank):
+    """Balanced contiguous partition of range(n): returns (begin, end) of `rank`."""
+    base, rem = divmod(n, world)
+    beg = rank * base + min(rank, rem)
+    return beg, beg + base + (1 if rank < rem else 0)
+
+
+class LabelShard:
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError('LabelShard needs torch.distributed to be initialised (one process per GPU)')
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def label_range(self, L):
+        return partition(L, self.world, self.rank)
+
+    def batch_split(self, B):
+        """(b0, b1) of this rank when the batch divides evenly, else None (replicated encoder)."""
+        if B % self.world != 0:
+            return None
+        return partition(B, self.world, self.rank)
+
+    # ---- collectives (tensors are contiguous) ---------------------------------------------------------------
+    def all_gather_batch(self, local):
+        """[B/P, ...] on every rank -> [B, ...]."""
+        out = local.new_empty((local.shape[0] * self.world,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        return out
+
+    def reduce_scatter_batch(self, full):
+        """[B, ...] partial sums on every rank -> this rank's summed [B/P, ...]."""
+        out = full.new_empty((full.shape[0] // self.world,) + tuple(full.shape[1:]))
+        dist.reduce_scatter_tensor(out, full.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def all_reduce_(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def all_gather_labels(self, local, L):
+        """[B, L_r] column shards (uneven allowed) -> [B, L]."""
+        B = local.shape[0]
+        width = (L + self.world - 1) // self.world
+        pad = local.new_zeros((width, B))
+        pad[:local.shape[1]] = local.t()
+        out = local.new_empty((self.world * width, B))
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        cols = []
+        for r in range(self.world):
+            b, e = partition(L, self.world, r)
+            cols.append(out[r * width: r * width + (e - b)])
+        return torch.cat(cols, 0).t().contiguous()
+
+
+class FlatGrads:
+    """Gradient tensors carved out of one flat buffer, so the shared-parameter all-reduce is a single collective."""
+
+    def __init__(self, P, names):
+        total = sum(P[k].numel() for k in names)
+        ref = P[names[0]]
+        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self.views = {}
+        off = 0
+        for k in names:
+            n = P[k].numel()
+            self.views[k] = self.flat[off:off + n].view_as(P[k])
+            off += n
+
+    def __getitem__(self, k):
+        return self.views[k]
+
+    def __contains__(self, k):
+        return k in self.views

@@ -1,0 +1,146 @@
+/* gzsl_hip.h - C ABI of libgzsl_hip.so: MI355X (gfx950) kernels for the gzsl_text hot path.
+ *
+ * The reference (petuum/gzsl_text) has no FFI of its own: its hot path is Python nn.Modules whose ops dispatch to
+ * ATen/cuDNN/cuBLAS.  Each entry point below names the reference statement(s) it replaces (path:line under the
+ * reference tree).  All pointers are DEVICE pointers to contiguous row-major buffers (fp32 unless said otherwise,
+ * token / label ids int64 as the reference's LongTensors); `stream` is a hipStream_t; nothing allocates or syncs.
+ * Return value: 0 on success, a hipError_t (>0) from the launch, or GZSL_EINVAL (1001) for unsupported arguments.
+ * The host side (gzsl_text_amd/, Python, mirroring the modules package) binds these with ctypes; see INTEGRATION.md.
+ */
+#ifndef GZSL_HIP_H
+#define GZSL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GZSL_ACT_NONE 0
+#define GZSL_ACT_RELU 1
+#define GZSL_ACT_TANH 2
+#define GZSL_ACT_LRELU 3 /* LeakyReLU(0.2), generative_module.py:46,61 */
+
+/* ---- dense contractions ---------------------------------------------------------------------------------------
+ * C[M,N] = act(alpha * A(M,K).B(K,N) + bias[n] + (accumulate ? C : 0)), exact-fp32 MFMA.
+ * Replaces nn.Conv1d (icd_modules.py:74,131 - implicit GEMM over k*E-float windows), nn.Linear
+ * (icd_modules.py:68,76,134,159; generative_module.py:44-45,59-60; decoder_module.py:29,40,43), nn.GRUCell's two
+ * GEMMs (graph_module.py:87,122) and the autograd products of all of them. */
+typedef struct GzslGemm {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias; /* [N] or NULL */
+    int M, N, K;
+    int a_mb;          /* m -> (m / a_mb, m % a_mb); >= M when A is not batched along m */
+    long long a_mbs;   /* elements between A batches */
+    int a_sm, a_sk;    /* element strides of A inside a batch */
+    int a_shift;       /* added to the in-batch offset (may be negative: conv data-gradient window start) */
+    unsigned a_span;   /* A element reads as 0 unless 0 <= in-batch offset < a_span */
+    int k_inner;       /* k -> (k / k_inner, k % k_inner); >= K when k is not batched; otherwise >= 32 */
+    long long a_kbs;   /* elements between A k-batches */
+    int b_sk, b_sn;    /* element strides of B */
+    long long b_kbs;   /* elements between B k-batches */
+    int ldc;
+    int act;
+    int accumulate;
+    float alpha;
+    int split_k;           /* > 1: blockIdx.z owns k_per_split of K and writes alpha*partial to C + z*slab_stride */
+    int k_per_split;       /* multiple of 32 */
+    long long slab_stride; /* elements */
+} GzslGemm;
+int gzsl_gemm(const GzslGemm* g, void* stream);
+/* out = act(sum_z slab[z] + bias) (+ out); unpack_k > 0 scatters a [(j*E+e), f] slab into conv weight layout [F,E,k] */
+int gzsl_splitk_reduce(const float* slab, long long slab_stride, int nsplit, float* out, int M, int N, int ldo,
+                       const float* bias, int act, int accumulate, int unpack_k, int unpack_e, void* stream);
+
+/* ---- fused label attention ------------------------------------------------------------------------------------
+ * icd_modules.py:137-142: scores, softmax over tokens, attn dropout(0.2), pooling - never materialising B x L x T'.
+ * PX [B,Tp,E] keys, X [B,Tp,F] values, Q [L,E] queries (this rank's label rows), O [B,L,F], LSE [B,L].
+ * Dropout: counter hash on (b, l_offset + l, t) with L_total as the row pitch (oracle/rng.py); drop_thresh = 0 disables. */
+int gzsl_label_attn_fwd(const float* PX, const float* X, const float* Q, float* O, float* LSE, int B, int Tp, int E,
+                        int F, int L, int l_offset, int L_total, uint32_t seed, uint32_t drop_thresh, float drop_scale,
+                        void* stream);
+/* delta[row] = sum_f dO[row,f] * O[row,f] (softmax-backward row constant), rows = B*L */
+int gzsl_attn_delta(const float* dO, const float* O, float* delta, long long rows, int F, void* stream);
+/* autograd of the above: dPX [B,Tp,E], dX [B,Tp,F], dQ [L,E] are ACCUMULATED with float atomics (caller zeroes or
+ * pre-loads them).  nsplit label splits per (note, 128-token tile) raise the workgroup count past 256 CUs. */
+int gzsl_label_attn_bwd(const float* dO, const float* PX, const float* X, const float* Q, const float* LSE,
+                        const float* DELTA, float* dPX, float* dX, float* dQ, int B, int Tp, int E, int F, int L,
+                        int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh, float drop_scale,
+                        void* stream);
+
+/* ---- embedding / label side -------------------------------------------------------------------------------------
+ * out[row,:] = W[ids[row],:] * mask[row] * dropout;  common_module.py:87-88 + icd_modules.py:153-157 (mask may be NULL).
+ * row_offset = global index of row 0 (b0*T when a rank encodes notes b0.. of the batch): the dropout hash is keyed on it. */
+int gzsl_emb_gather_fwd(const float* W, const int64_t* ids, const float* mask, float* out, long long rows, int E,
+                        long long row_offset, uint32_t seed, uint32_t drop_thresh, float drop_scale, void* stream);
+/* dW[ids[row],:] += dOut[row,:] * mask[row] * dropout, skipping ids == pad_idx (nn.Embedding padding_idx, common_module.py:76) */
+int gzsl_emb_scatter_add(float* dW, const int64_t* ids, const float* mask, const float* dOut, long long rows, int E,
+                         int64_t pad_idx, long long row_offset, uint32_t seed, uint32_t drop_thresh, float drop_scale,
+                         void* stream);
+/* icd_modules.py:110-113 average_label_embedding: out[n,:] = sum_j mask[n,j] W[idx[n,j],:] / sum_j mask[n,j] */
+int gzsl_label_avg_fwd(const float* W, const int64_t* idx, const float* mask, float* out, int N, int Td, int E,
+                       void* stream);
+int gzsl_label_avg_bwd(float* dW, const float* davg, const int64_t* idx, const float* mask, int N, int Td, int E,
+                       int64_t pad_idx, void* stream);
+/* graph_module.py:114-117 (and :70-73): out[n,:] (+)= post[n] * sum_p val[p] * pre[col[p]] * x[col[p],:]  over CSR row n;
+ * pre/post may be NULL (=1).  post = 1/(deg+1e-7) gives the neighbour mean; pre with the transposed CSR gives its adjoint. */
+int gzsl_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, const float* x, const float* pre,
+                  const float* post, float* out, int N, int H, int accumulate, void* stream);
+/* nn.GRUCell gate math (graph_module.py:122) after the two GEMMs gi = u.Wih^T + bih, gh = h.Whh^T + bhh ([N,3H], r|z|n) */
+int gzsl_gru_gate_fwd(const float* gi, const float* gh, const float* h, float* hn, int N, int H, void* stream);
+int gzsl_gru_gate_bwd(const float* dhn, const float* gi, const float* gh, const float* h, float* dgi, float* dgh,
+                      float* dh, int N, int H, void* stream);
+
+/* ---- classifier head + loss -------------------------------------------------------------------------------------
+ * icd_modules.py:177-182 (and :263-272): logits[b,l] = sum_d clf[l,d] * relu(direct[b,l,d]) */
+int gzsl_logits_fwd(const float* direct, const float* clf, float* logits, int B, int L, int D, void* stream);
+/* ddirect[b,l,d] = dlogits[b,l] * clf[l,d] * (direct > 0);  dclf[l,d] (+)= sum_b dlogits[b,l] * relu(direct[b,l,d]) */
+int gzsl_logits_bwd(const float* direct, const float* clf, const float* dlogits, float* ddirect, float* dclf, int B,
+                    int L, int D, int accumulate_dclf, void* stream);
+/* icd_modules.py:162-172 + BCEWithLogitsLoss(sum) common_module.py:29-30: z = logit - y*margin[l]*C;
+ * *loss += sum bce(z,y) * inv_b (atomic; caller zeroes); dlogits = (sigmoid(z) - y) * inv_b.  margin may be NULL. */
+int gzsl_ldam_bce(const float* logits, const float* y, const float* margin, float C, float inv_b, float* loss,
+                  float* dlogits, float* probs, int B, int L, void* stream);
+/* icd_modules.py:233-249 forward_final: z_i = <fc[lab_i,:], feat_i> - margin[lab_i]*C; *loss += sum bce(z,1)*scale;
+ * dfc[lab_i,:] += (sigmoid(z_i)-1)*scale*feat_i (atomic); dfeat may be NULL */
+int gzsl_forward_final(const float* fc, const float* feats, const int64_t* labels, const float* margin, float C,
+                       float scale, float* loss, float* dfc, float* dfeat, int Bs, int D, void* stream);
+/* common_module.py:138-182 AdamW.step (no bias correction, eps added to sqrt(v), wd on the parameter) */
+int gzsl_adamw_nobias_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                           float beta2, float eps, float wd, void* stream);
+
+/* ---- small elementwise / reductions used by the backward passes ------------------------------------------------ */
+int gzsl_act_bwd(float* d, const float* y, long long n, int act, void* stream); /* d *= act'(y), y = activated output */
+int gzsl_colsum(const float* x, float* out, long long M, int N, int ld, void* stream); /* out[n] += sum_m x[m*ld+n] */
+/* conv_modules.0.weight [F,E,k] -> Wp[f][j*E+e] (forward GEMM operand) and Wflip[e][j'*F+f] = W[f][e][k-1-j'] (data grad) */
+int gzsl_conv_weight_pack(const float* W, float* Wp, float* Wflip, int F, int E, int k, void* stream);
+
+/* ---- WGAN-GP step ---------------------------------------------------------------------------------------------
+ * generative_module.py:27 interpolates = alpha*real + (1-alpha)*fake, alpha [Bg] */
+int gzsl_gp_interp(const float* real, const float* fake, const float* alpha, float* out, int Bg, int D, void* stream);
+/* closed-form gradient penalty pieces (generative_module.py:22-38): v[b,j] = slope(h[b,j]) * w2[j], slope in {1,0.2} */
+int gzsl_gp_slope_v(const float* h, const float* w2, float* v, float* s, int Bg, int H, void* stream);
+/* nrm_b = ||g_b||; *gp += lam*(nrm_b-1)^2/Bg (atomic); g_b <- (2*lam*(nrm_b-1)/(Bg*nrm_b)) * g_b  (in place) */
+int gzsl_gp_rownorm(float* g, float* gp, int Bg, int D, float lam, void* stream);
+/* dw2[j] += sum_b dv[b,j]*s[b,j] */
+int gzsl_gp_dw2(const float* dv, const float* s, float* dw2, int Bg, int H, void* stream);
+/* out[b] = dot(a[b,:], w) + bias0 (critic fc2 with one output, generative_module.py:60,67-68); bias may be NULL */
+int gzsl_rowdot(const float* a, const float* w, const float* bias, float* out, int Bg, int H, void* stream);
+/* *out += sum_b x[b] * w[b] * scale (critic means, train_gan.py:244,252,300); w may be NULL */
+int gzsl_weighted_sum(const float* x, const float* w, float scale, float* out, int n, void* stream);
+/* da[b,j] = dout[b] * w[j] * slope(act[b,j]);  dw[j] += sum_b dout[b]*act[b,j];  db += sum_b dout[b]  (fc2 backward, one output) */
+int gzsl_rowdot_bwd(const float* dout, const float* w, const float* act, float* da, float* dw, float* db, int Bg,
+                    int H, void* stream);
+/* decoder_module.py:39-59 soft-target cross-entropy over the keyword vocabulary: loss_b = -sum_v log_softmax(logits)[b,v]*t[b,v],
+ * t = normalised mask scattered by assignment (last duplicate wins).  Writes loss_b and, in place, dlogits = w_b*(softmax*sum(t) - t). */
+int gzsl_keyword_ce(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* w, float* loss_b, int Bg,
+                    int Vk, int top_k, void* stream);
+
+/* library self-description: number of exported compute entry points and build target string */
+const char* gzsl_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GZSL_HIP_H */

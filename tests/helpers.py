@@ -1,0 +1,67 @@
+"""Shared helpers for the parity tests (CPU stand-in and GPU)."""
+import numpy as np
+import torch
+
+from gzsl_text_amd.modules.common_module import get_loss_fn
+from gzsl_text_amd.modules.icd_modules import ConvLabelAttnGAN, ConvLabelAttnModel
+from tests.golden import synth
+
+
+def close(a, b, rtol, atol, what):
+    a = np.asarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().cpu().numpy() if torch.is_tensor(b) else b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), f'{what}: non-finite values'
+    err = np.abs(a - b)
+    bad = err > atol + rtol * np.abs(b)
+    assert not bad.any(), (f'{what}: max err {err.max():.3e} (ref max {np.abs(b).max():.3e}), '
+                           f'{int(bad.sum())}/{bad.size} outside rtol={rtol} atol={atol}')
+
+
+def build_model(case, cls=ConvLabelAttnModel, device='cpu', ops=None, sparse=True, C=2.0):
+    """Construct the mirror module exactly as train_base.py:76-84 does and load the synthetic parameters."""
+    d = case['dims']
+    bufs = case['bufs']
+    rows, cols, vals, N = bufs['adj_matrix']
+    adj = torch.from_numpy(synth.coo_to_dense(rows, cols, vals, N))
+    model = cls(case['params']['emb.embed.weight'].copy(), torch.from_numpy(bufs['code_idx_matrix']),
+                torch.from_numpy(bufs['code_idx_mask']), adj, torch.from_numpy(bufs['num_neighbors']),
+                get_loss_fn('bce', reduction='sum'), num_filters=d['F'], kernel_sizes=(d['k'],),
+                eval_code_size=d['L'], label_hidden_size=d['H'], graph_encoder=case['encoder'],
+                target_count=case['target_count'].copy(), C=C)
+    sd = model.state_dict()
+    for k, v in case['params'].items():
+        assert k in sd and tuple(sd[k].shape) == v.shape, (k, v.shape)
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd)
+    if sparse:
+        model.adj_matrix = model.adj_matrix.to_sparse()  # train_base.py:79
+    model.to(device)
+    if ops is not None:
+        model.use_ops(ops)
+    return model
+
+
+def batch_tensors(case, device='cpu'):
+    return tuple(torch.from_numpy(case[k]).to(device) for k in ('x', 'y', 'mask'))
+
+
+def check_base_against_golden(model, case, g, train, device='cpu', grad_atol=None):
+    d = case['dims']
+    x, y, mask = batch_tensors(case, device)
+    if train:
+        model.train()
+        model.set_dropout_seed(synth.DROP_SEED)
+    else:
+        model.eval()
+    model.zero_grad()
+    avg, graph = model.get_label_embedding()
+    close(avg, g['avg'], 1e-5, 1e-6, 'avg label emb')
+    close(graph, g['graph'], 1e-5, 2e-6, 'graph label emb')
+    logits, loss = model(x, y, mask)
+    loss.mean().backward()
+    close(logits, g['logits'], 1e-5, 2e-5, 'logits')
+    close(loss, g['loss'], 1e-5, 1e-5, 'loss')
+    atol = grad_atol if grad_atol is not None else (2e-6 if d['T'] > 64 else 1e-6)
+    for k, p in model.named_parameters():
+        close(p.grad, g['grad.' + k], 1e-4, atol, 'grad ' + k)

@@ -1,0 +1,287 @@
+"""GPU parity tests: every HIP kernel (through the C ABI, via gzsl_text_amd.ops_hip.HipOps) against the plain
+torch-fp32 statement of the same op (tests/ops_cpu.py) on identical seeded inputs.
+
+Tolerances are fp32 (north star: "within a stated fp32 tolerance"): forward values rtol 1e-5 / atol 1e-5 scaled to the
+data, reductions over K terms atol ~ K * 1e-7 * typical magnitude; stated per check.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import close
+from tests.ops_cpu import CpuOps
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gzsl_text_amd.ops_hip import HipOps
+    return HipOps()
+
+
+@pytest.fixture(scope='module')
+def ref():
+    return CpuOps()
+
+
+def rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+def g(t):
+    return None if t is None else t.to(DEV)
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (37, 53, 19), (128, 128, 32), (300, 200, 1000), (129, 100, 200),
+                                   (1000, 300, 70), (64, 800, 800)])
+@pytest.mark.parametrize('ta,tb', [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_all_layouts(ops, ref, M, N, K, ta, tb):
+    rs = np.random.RandomState(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = rnd(rs, K, M).t() if ta else rnd(rs, M, K)
+    B = rnd(rs, N, K).t() if tb else rnd(rs, K, N)
+    bias = rnd(rs, N)
+    Ad, Bd = (g(A.t().contiguous()).t() if ta else g(A)), (g(B.t().contiguous()).t() if tb else g(B))
+    for act in (0, 1, 2, 3):
+        out = ops.mm(Ad, Bd, bias=g(bias), act=act)
+        close(out, ref.mm(A, B, bias=bias, act=act), 2e-5, 2e-5 * np.sqrt(K), f'mm act={act}')
+    C0 = rnd(rs, M, N)
+    out = ops.mm(Ad, Bd, out=g(C0).clone(), accumulate=True, alpha=0.5)
+    close(out, ref.mm(A, B, out=C0.clone(), accumulate=True, alpha=0.5), 2e-5, 2e-5 * np.sqrt(K), 'mm accumulate')
+
+
+def test_gemm_split_k_and_strided_output(ops, ref):
+    rs = np.random.RandomState(5)
+    M, N, K = 100, 200, 20000
+    A, B = rnd(rs, K, M), rnd(rs, K, N)
+    out = ops.mm(g(A).t(), g(B))  # weight-gradient shape: small output, huge K -> split-K slabs
+    close(out, A.t() @ B, 2e-5, 3e-3, 'split-K TN')
+    big = torch.zeros(M, N + 50)
+    bigd = g(big).clone()
+    ops.mm(g(A).t(), g(B), out=bigd[:, :N], accumulate=True)
+    big[:, :N] += A.t() @ B
+    close(bigd, big, 2e-5, 3e-3, 'split-K into a column slice (ldc > N)')
+
+
+@pytest.mark.parametrize('B,T,E,F,k', [(3, 40, 8, 24, 10), (2, 33, 8, 20, 10), (2, 300, 100, 200, 10), (1, 75, 100, 200, 10),
+                                       (4, 64, 12, 40, 3)])
+def test_conv_fwd_bwd(ops, ref, B, T, E, F, k):
+    rs = np.random.RandomState(B + T + E)
+    e, W, b = rnd(rs, B, T, E), rnd(rs, F, E, k, scale=0.1), rnd(rs, F, scale=0.1)
+    X = ops.conv_relu(g(e), g(W), g(b))
+    Xr = ref.conv_relu(e, W, b)
+    close(X, Xr, 2e-5, 2e-5, 'conv+relu')
+    dY = rnd(rs, B, T - k + 1, F) * (Xr > 0).float()
+    de, dW, db = ops.conv_bwd(g(dY), g(e), g(W))
+    der, dWr, dbr = ref.conv_bwd(dY, e, W)
+    close(de, der, 2e-5, 5e-5, 'conv data grad')
+    close(dW, dWr, 2e-5, 1e-4 * np.sqrt(B * T / 100), 'conv weight grad')
+    close(db, dbr, 2e-5, 1e-4 * np.sqrt(B * T / 100), 'conv bias grad')
+
+
+@pytest.mark.parametrize('p', [0.0, 0.5])
+def test_embedding_gather_scatter(ops, ref, p):
+    rs = np.random.RandomState(3)
+    V, E, B, T = 50, 100, 4, 37
+    W = rnd(rs, V, E)
+    ids = torch.from_numpy(rs.randint(0, V, size=(B, T)).astype(np.int64))
+    mask = torch.from_numpy((rs.random_sample((B, T)) < 0.8).astype(np.float32))
+    out = ops.emb_gather(g(W), g(ids), g(mask), 77, p, row_offset=11)
+    close(out, ref.emb_gather(W, ids, mask, 77, p, row_offset=11), 0, 0, 'emb gather (bit exact)')
+    dOut = rnd(rs, B, T, E)
+    dW = ops.emb_scatter_add_(torch.zeros(V, E, device=DEV), g(ids), g(mask), g(dOut), 77, p, row_offset=11)
+    close(dW, ref.emb_scatter_add_(torch.zeros(V, E), ids, mask, dOut, 77, p, row_offset=11), 1e-5, 1e-5, 'emb scatter')
+    assert float(dW[0].abs().sum()) == 0.0, 'padding row must get no gradient'
+
+
+def test_label_side_kernels(ops, ref):
+    rs = np.random.RandomState(4)
+    V, E, N, Td, H = 60, 100, 45, 7, 100
+    W = rnd(rs, V, E)
+    lens = rs.randint(1, Td + 1, size=N)
+    cm = torch.from_numpy((np.arange(Td)[None] < lens[:, None]).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(1, V, size=(N, Td)).astype(np.int64)) * cm.long()
+    avg = ops.label_avg(g(W), g(idx), g(cm))
+    close(avg, ref.label_avg(W, idx, cm), 1e-6, 1e-6, 'label avg')
+    davg = rnd(rs, N, E)
+    dW = ops.label_avg_bwd_(torch.zeros(V, E, device=DEV), g(davg), g(idx), g(cm))
+    close(dW, ref.label_avg_bwd_(torch.zeros(V, E), davg, idx, cm), 1e-5, 1e-5, 'label avg bwd')
+    from gzsl_text_amd.engine import build_csr
+    from tests.golden import synth
+    rows, cols, vals, deg = synth.forest_adjacency(rs, N)
+    adj = torch.from_numpy(synth.coo_to_dense(rows, cols, vals, N))
+    csr, csr_t = build_csr(adj.to_sparse())
+    csr_d, csr_td = build_csr(adj.to(DEV).to_sparse())
+    inv = torch.from_numpy(1.0 / (deg + 1e-7))
+    x = rnd(rs, N, H)
+    close(ops.spmm(csr_d, g(x), post=g(inv)), ref.spmm(csr, x, post=inv), 1e-6, 1e-6, 'spmm mean')
+    acc = rnd(rs, N, H)
+    close(ops.spmm(csr_td, g(x), pre=g(inv), out=g(acc).clone(), accumulate=True),
+          ref.spmm(csr_t, x, pre=inv, out=acc.clone(), accumulate=True), 1e-6, 1e-6, 'spmm adjoint accumulate')
+    gi, gh, h, dhn = rnd(rs, N, 3 * H), rnd(rs, N, 3 * H), rnd(rs, N, H), rnd(rs, N, H)
+    close(ops.gru_gate_fwd(g(gi), g(gh), g(h)), ref.gru_gate_fwd(gi, gh, h), 1e-5, 1e-6, 'gru gate fwd')
+    for a, b, nm in zip(ops.gru_gate_bwd(g(dhn), g(gi), g(gh), g(h)), ref.gru_gate_bwd(dhn, gi, gh, h),
+                        ('dgi', 'dgh', 'dh')):
+        close(a, b, 1e-5, 1e-6, 'gru gate bwd ' + nm)
+
+
+ATTN_SHAPES = [
+    # B, Tp, E, F, L
+    (2, 31, 8, 24, 12),     # golden tiny shape
+    (1, 5, 8, 20, 3),       # fewer tokens than one tile, fewer labels than one MFMA tile
+    (2, 291, 100, 200, 256),  # golden medium shape: Tp not a multiple of 32
+    (3, 100, 100, 200, 77),   # L not a multiple of 64 or 16
+    (8, 64, 100, 200, 130),   # B multiple of 8 -> XCD-aware block mapping
+    (2, 150, 200, 200, 40),   # real E = 200 class
+    (2, 70, 50, 100, 33),     # sizes strictly inside a shape class (zero-padded operands)
+]
+
+
+@pytest.mark.parametrize('B,Tp,E,F,L', ATTN_SHAPES)
+@pytest.mark.parametrize('p', [0.0, 0.2])
+def test_label_attention_fwd_bwd(ops, ref, B, Tp, E, F, L, p):
+    rs = np.random.RandomState(B * 1000 + Tp + L)
+    PX = torch.tanh(rnd(rs, B, Tp, E))
+    X = torch.relu(rnd(rs, B, Tp, F))
+    Q = rnd(rs, L, E, scale=0.3)
+    l_off, L_tot, seed = 5, L + 9, 4321
+    O, lse = ops.attn_fwd(g(PX), g(X), g(Q), l_off, L_tot, seed, p)
+    Or, lser = ref.attn_fwd(PX, X, Q, l_off, L_tot, seed, p)
+    close(lse, lser, 1e-5, 1e-5, 'attention log-sum-exp')
+    close(O, Or, 2e-5, 2e-5, 'attention output')
+    dO = rnd(rs, B, L, F)
+    dPX, dX, dQ = torch.zeros(B, Tp, E, device=DEV), torch.zeros(B, Tp, F, device=DEV), torch.zeros(L, E, device=DEV)
+    ops.attn_bwd(g(dO), O, g(PX), g(X), g(Q), lse, l_off, L_tot, seed, p, dPX, dX, dQ)
+    dPXr, dXr, dQr = torch.zeros(B, Tp, E), torch.zeros(B, Tp, F), torch.zeros(L, E)
+    ref.attn_bwd(dO, Or, PX, X, Q, lser, l_off, L_tot, seed, p, dPXr, dXr, dQr)
+    close(dX, dXr, 1e-4, 2e-5 * np.sqrt(L), 'attention dX')
+    close(dPX, dPXr, 1e-4, 2e-5 * np.sqrt(L), 'attention dPX')
+    close(dQ, dQr, 1e-4, 2e-5 * np.sqrt(B * Tp), 'attention dQ')
+    # label splits must not change the result beyond summation order
+    dPX2, dX2, dQ2 = torch.zeros_like(dPX), torch.zeros_like(dX), torch.zeros_like(dQ)
+    ops.attn_bwd(g(dO), O, g(PX), g(X), g(Q), lse, l_off, L_tot, seed, p, dPX2, dX2, dQ2, nsplit=3)
+    close(dX2, dX, 1e-5, 1e-5, 'attention dX, nsplit=3')
+    close(dQ2, dQ, 1e-5, 1e-5, 'attention dQ, nsplit=3')
+
+
+def test_label_attention_online_softmax_rescale_branch(ops, ref):
+    """Force the lazy-rescale branch (cdna guide rule 26): one key late in the sequence dominates the running max by
+    far more than the rescale threshold, for only some labels."""
+    rs = np.random.RandomState(9)
+    B, Tp, E, F, L = 1, 200, 100, 200, 70
+    PX = torch.tanh(rnd(rs, B, Tp, E, scale=0.2))
+    X = torch.relu(rnd(rs, B, Tp, F))
+    Q = rnd(rs, L, E, scale=0.2)
+    PX[0, 150] = torch.sign(Q[3])          # score for label 3 jumps to ||q_3||_1 ~ 16 at token 150
+    Q[3] *= 3.0
+    PX[0, 170] = torch.sign(Q[40]) * 0.99  # and for label 40 at token 170
+    Q[40] *= 5.0
+    O, lse = ops.attn_fwd(g(PX), g(X), g(Q), 0, L, 0, 0.0)
+    Or, lser = ref.attn_fwd(PX, X, Q, 0, L, 0, 0.0)
+    assert float(lser.max()) > 40, 'test input must exceed the rescale threshold'
+    close(lse, lser, 1e-5, 1e-5, 'lse with forced rescale')
+    close(O, Or, 2e-5, 2e-5, 'output with forced rescale')
+
+
+def test_label_attention_shard_invariance(ops):
+    """Rows [l0, l1) of a sharded call equal the same rows of the unsharded call (dropout keyed on global coordinates).
+    Not bit for bit: the lazy-rescale decision is taken per wave, so a label's rounding depends on its 15 neighbours."""
+    rs = np.random.RandomState(10)
+    B, Tp, E, F, L = 2, 90, 100, 200, 150
+    PX, X, Q = g(torch.tanh(rnd(rs, B, Tp, E))), g(torch.relu(rnd(rs, B, Tp, F))), g(rnd(rs, L, E, scale=0.3))
+    O, lse = ops.attn_fwd(PX, X, Q, 0, L, 99, 0.2)
+    for l0, l1 in ((0, 75), (75, 150), (10, 31)):
+        Os, lses = ops.attn_fwd(PX, X, Q[l0:l1].contiguous(), l0, L, 99, 0.2)
+        close(Os, O[:, l0:l1], 1e-5, 1e-6, f'shard [{l0},{l1}) output')
+        close(lses, lse[:, l0:l1], 1e-6, 1e-6, f'shard [{l0},{l1}) lse')
+
+
+def test_head_and_loss_kernels(ops, ref):
+    rs = np.random.RandomState(6)
+    B, L, D = 5, 77, 200
+    direct, clf = rnd(rs, B, L, D), rnd(rs, L, D, scale=0.2)
+    logits = ops.logits_fwd(g(direct), g(clf))
+    lr_ = ref.logits_fwd(direct, clf)
+    close(logits, lr_, 1e-5, 2e-5, 'logits')
+    y = torch.from_numpy((rs.random_sample((B, L)) < 0.1).astype(np.float32))
+    margin = torch.from_numpy(rs.uniform(0.2, 1.0, L).astype(np.float32))
+    for m, C in ((margin, 2.0), (None, 0.0)):
+        loss, dl, probs = ops.ldam_bce(logits, g(y), g(m), C, 1.0 / B, need_probs=True)
+        lossr, dlr, probsr = ref.ldam_bce(lr_, y, m, C, 1.0 / B, need_probs=True)
+        close(loss, lossr, 1e-5, 1e-4, 'ldam bce loss')
+        close(dl, dlr, 1e-5, 1e-7, 'ldam bce dlogits')
+        close(probs, probsr, 1e-5, 1e-6, 'sigmoid scores')
+    dd, dclf = ops.logits_bwd(g(direct), g(clf), dl)
+    ddr, dclfr = ref.logits_bwd(direct, clf, dlr)
+    close(dd, ddr, 1e-5, 1e-7, 'ddirect')
+    close(dclf, dclfr, 1e-5, 1e-6, 'dclf')
+    Bs = 33
+    fc, feats = rnd(rs, L, D, scale=0.2), torch.relu(rnd(rs, Bs, D))
+    labs = torch.from_numpy(rs.randint(0, L, size=Bs).astype(np.int64))
+    labs[1] = labs[0]
+    loss, dfc = ops.forward_final(g(fc), g(feats), g(labs), g(margin), 2.0, 1.0 / Bs)
+    lossr, dfcr = ref.forward_final(fc, feats, labs, margin, 2.0, 1.0 / Bs)
+    close(loss, lossr, 1e-5, 1e-5, 'forward_final loss')
+    close(dfc, dfcr, 1e-5, 1e-6, 'forward_final dfc')
+    p, gr, m_, v_ = rnd(rs, L, D), rnd(rs, L, D, scale=0.01), rnd(rs, L, D, scale=0.01), rnd(rs, L, D, scale=0.01).abs()
+    pd, md, vd = g(p).clone(), g(m_).clone(), g(v_).clone()
+    ops.adamw_step_(pd, g(gr), md, vd, 1e-3, 0.5, 0.999, 1e-6, 5e-4)
+    ref.adamw_step_(p, gr, m_, v_, 1e-3, 0.5, 0.999, 1e-6, 5e-4)
+    close(pd, p, 1e-6, 1e-7, 'adamw p')
+    close(md, m_, 1e-6, 1e-8, 'adamw m')
+    close(vd, v_, 1e-6, 1e-9, 'adamw v')
+
+
+def test_small_helpers(ops, ref):
+    rs = np.random.RandomState(8)
+    x = rnd(rs, 5000, 300)
+    close(ops.colsum(g(x)), x.sum(0), 1e-5, 2e-3, 'colsum')
+    close(ops.colsum(g(x)[:, :100]), x[:, :100].sum(0), 1e-5, 2e-3, 'colsum strided')
+    for act in (1, 2, 3):
+        y, d = (torch.tanh(rnd(rs, 1000, 7)) if act == 2 else rnd(rs, 1000, 7)), rnd(rs, 1000, 7)
+        close(ops.act_bwd_(g(d).clone(), g(y), act), ref.act_bwd_(d.clone(), y, act), 1e-6, 1e-7, f'act bwd {act}')
+
+
+def test_gan_kernels(ops, ref):
+    rs = np.random.RandomState(12)
+    Bg, D, H, Vk, K = 70, 400, 800, 300, 20
+    real, fake, alpha = rnd(rs, Bg, D), rnd(rs, Bg, D), torch.from_numpy(rs.random_sample(Bg).astype(np.float32))
+    close(ops.gp_interp(g(real), g(fake), g(alpha)), ref.gp_interp(real, fake, alpha), 1e-6, 1e-6, 'interp')
+    h, w2 = rnd(rs, Bg, H), rnd(rs, H)
+    for a, b, nm in zip(ops.gp_slope_v(g(h), g(w2)), ref.gp_slope_v(h, w2), 'vs'):
+        close(a, b, 0, 0, 'gp ' + nm)
+    gg = rnd(rs, Bg, D, scale=0.1)
+    ggd = g(gg).clone()
+    gp = ops.gp_rownorm_(ggd, 10.0)
+    gpr = ref.gp_rownorm_(gg, 10.0)
+    close(gp, gpr, 1e-5, 1e-5, 'gp value')
+    close(ggd, gg, 1e-5, 1e-7, 'gp dg')
+    dv, s = rnd(rs, Bg, H), ref.gp_slope_v(h, w2)[1]
+    dw2 = torch.zeros(H, device=DEV)
+    ops.gp_dw2_(g(dv), g(s), dw2)
+    close(dw2, (dv * s).sum(0), 1e-5, 1e-5, 'gp dw2')
+    bias = rnd(rs, 1)
+    close(ops.rowdot(g(h), g(w2), g(bias)), ref.rowdot(h, w2, bias), 1e-5, 1e-4, 'rowdot')
+    wgt = rnd(rs, Bg)
+    close(ops.weighted_sum(g(wgt), g(alpha), 0.3), ref.weighted_sum(wgt, alpha, 0.3), 1e-5, 1e-5, 'weighted sum')
+    dout = rnd(rs, Bg)
+    dw, db = torch.zeros(H, device=DEV), torch.zeros(1, device=DEV)
+    dwr, dbr = torch.zeros(H), torch.zeros(1)
+    da = ops.rowdot_bwd(g(dout), g(w2), g(h), dw, db)
+    dar = ref.rowdot_bwd(dout, w2, h, dwr, dbr)
+    close(da, dar, 1e-6, 1e-7, 'rowdot bwd da')
+    close(dw, dwr, 1e-5, 1e-4, 'rowdot bwd dw')
+    close(db, dbr, 1e-5, 1e-5, 'rowdot bwd db')
+    logits = rnd(rs, Bg, Vk)
+    kw_idx = torch.from_numpy(np.stack([rs.choice(Vk, size=K, replace=False) for _ in range(Bg)]).astype(np.int64))
+    kw_idx[:, 5] = kw_idx[:, 2]  # duplicates: assignment semantics, last one wins
+    kw_mask = torch.from_numpy(rs.uniform(0, 1, (Bg, K)).astype(np.float32))
+    w = torch.from_numpy(rs.uniform(0, 1, Bg).astype(np.float32))
+    ld = g(logits).clone()
+    lb = ops.keyword_ce_(ld, g(kw_idx), g(kw_mask), g(w))
+    lr2 = logits.clone()
+    lbr = ref.keyword_ce_(lr2, kw_idx, kw_mask, w)
+    close(lb, lbr, 1e-5, 1e-5, 'keyword CE loss')
+    close(ld, lr2, 1e-5, 1e-6, 'keyword CE dlogits')
