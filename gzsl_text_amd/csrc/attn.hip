@@ -37,10 +37,15 @@ struct AttnFwdArgs {
     float scale;
 };
 
-template <int ES, int NFT>
-__global__ __launch_bounds__(FWD_WAVES * 64) void label_attn_fwd_kernel(AttnFwdArgs a) {
+// G = floats per staging load (4 when E and F are multiples of 4: 16-byte loads of the contiguous 32-row tile).
+template <int ES, int NFT, int G>
+__global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnFwdArgs a) {
     constexpr int EP = 4 * ES + 2;    // K row stride: 2*(odd) -> 16 rows x 2 k-lanes hit 32 distinct banks
     constexpr int FP = 16 * NFT + 4;  // V row stride: = 4 mod 8 -> rows 4q and 4q+4 land 16 banks apart
+    constexpr int NT = FWD_WAVES * 64;
+    constexpr int NKL = (FWD_BT * 4 * ES / G + NT - 1) / NT;   // staging loads per thread (keys)
+    constexpr int NVL = (FWD_BT * 16 * NFT / G + NT - 1) / NT;  // (values)
+    typedef float vecG __attribute__((ext_vector_type(G)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Ks = reinterpret_cast<float*>(smem_raw);
     float* Vs = Ks + FWD_BT * EP;
@@ -65,17 +70,31 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void label_attn_fwd_kernel(AttnFwdA
     const int lbl = lt * 16 * FWD_WAVES + wave * 16 + lr;  // this lane's label (column)
     const bool lbl_ok = lbl < a.L;
 
-    // Q^T fragment: B operand of S^T = K.Q^T ; qreg[s] = Q[lbl][4s + lq]
+    // Q^T fragment: B operand of S^T = K.Q^T ; qreg[s] = Q[lbl][4s + lq]   (clamped address + select: no branches)
     float qreg[ES];
+    {
+        const float* qrow = a.Q + (long long)min(lbl, a.L - 1) * a.E;
 #pragma unroll
-    for (int s = 0; s < ES; ++s) {
-        int e = 4 * s + lq;
-        qreg[s] = (lbl_ok && e < a.E) ? a.Q[(long long)lbl * a.E + e] : 0.f;
+        for (int s = 0; s < ES; ++s) {
+            const int e = 4 * s + lq;
+            qreg[s] = qrow[min(e, a.E - 1)] * ((lbl_ok && e < a.E) ? 1.f : 0.f);
+        }
     }
-    // zero the K pad columns once (tile loads never touch them) so 0 * garbage cannot make NaN
-    for (int i = tid; i < FWD_BT * (EP - a.E); i += FWD_WAVES * 64) {
-        int r = i / (EP - a.E), c = a.E + i % (EP - a.E);
-        Ks[r * EP + c] = 0.f;
+    // zero both tiles once: pad columns are never written by the staging copy and must not hold NaN patterns
+    for (int i = tid; i < FWD_BT * (EP + FP); i += NT) Ks[i] = 0.f;
+
+    // the 32-row tile of keys (values) is one contiguous block of 32*E (32*F) floats: copy it flat, G floats per
+    // load, and re-stride into the padded LDS rows.  LDS offsets are loop-invariant: computed once.
+    int kofs[NKL], vofs[NVL];
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+        const int f = (tid + NT * i) * G;
+        kofs[i] = (f < FWD_BT * a.E) ? (f / a.E) * EP + f % a.E : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+        const int f = (tid + NT * i) * G;
+        vofs[i] = (f < FWD_BT * a.F) ? (f / a.F) * FP + f % a.F : -1;
     }
 
     const uint32_t rowkey = gz_row_key(a.seed, GZSL_STREAM_ATTN, (uint32_t)b * (uint32_t)a.L_total + (uint32_t)(a.l_offset + lbl));
@@ -87,16 +106,53 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void label_attn_fwd_kernel(AttnFwdA
     const float* PXb = a.PX + (long long)b * a.Tp * a.E;
     const float* Xb = a.X + (long long)b * a.Tp * a.F;
 
-    for (int t0 = 0; t0 < a.Tp; t0 += FWD_BT) {
-        __syncthreads();  // previous tile fully consumed
-        // stage K/V rows t0..t0+31 (rows past Tp are zero-filled: 0 * P must stay 0)
-        for (int r = wave; r < FWD_BT; r += FWD_WAVES) {
-            const int t = t0 + r;
-            const bool ok = t < a.Tp;
-            for (int c = lane; c < a.E; c += 64) Ks[r * EP + c] = ok ? PXb[(long long)t * a.E + c] : 0.f;
-            for (int c = lane; c < 16 * NFT; c += 64) Vs[r * FP + c] = (ok && c < a.F) ? Xb[(long long)t * a.F + c] : 0.f;
+    vecG kreg[NKL], vreg[NVL];
+    // global -> registers; stays in flight while the previous tile is computed.  Clamped addresses, no validity
+    // selects (a `cond ? load : 0` makes hipcc branch around the load and wait inside the branch): rows past Tp hold
+    // finite neighbouring data whose scores are masked to -inf below, so their P is exactly 0.
+    auto issue = [&](int t0) {
+        const int rows = min(FWD_BT, a.Tp - t0);
+        const int nk = rows * a.E, nv = rows * a.F;
+        const float* kb = PXb + (long long)t0 * a.E;
+        const float* vb = Xb + (long long)t0 * a.F;
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) kreg[i] = *reinterpret_cast<const vecG*>(kb + min((tid + NT * i) * G, nk - G));
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) vreg[i] = *reinterpret_cast<const vecG*>(vb + min((tid + NT * i) * G, nv - G));
+    };
+    auto commit = [&]() {  // registers -> LDS
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            if (kofs[i] >= 0) {
+                if constexpr (G == 4) {
+                    float2* d = reinterpret_cast<float2*>(Ks + kofs[i]);
+                    d[0] = make_float2(kreg[i][0], kreg[i][1]);
+                    d[1] = make_float2(kreg[i][2], kreg[i][3]);
+                } else {
+                    Ks[kofs[i]] = kreg[i][0];
+                }
+            }
         }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            if (vofs[i] >= 0) {
+                if constexpr (G == 4) {
+                    float2* d = reinterpret_cast<float2*>(Vs + vofs[i]);
+                    d[0] = make_float2(vreg[i][0], vreg[i][1]);
+                    d[1] = make_float2(vreg[i][2], vreg[i][3]);
+                } else {
+                    Vs[vofs[i]] = vreg[i][0];
+                }
+            }
+        }
+    };
+
+    issue(0);
+    for (int t0 = 0; t0 < a.Tp; t0 += FWD_BT) {
+        __syncthreads();  // previous tile fully consumed (first pass: zero fill done)
+        commit();
         __syncthreads();
+        if (t0 + FWD_BT < a.Tp) issue(t0 + FWD_BT);
 #pragma unroll
         for (int u = 0; u < FWD_BT / 16; ++u) {
             // S^T sub-tile: rows = tokens t0+16u+4lq+r, cols = labels
@@ -136,12 +192,13 @@ __global__ __launch_bounds__(FWD_WAVES * 64) void label_attn_fwd_kernel(AttnFwdA
                     p[r] = (uu >= a.thresh) ? p[r] * a.scale : 0.f;
                 }
             }
-            // O^T[f, label] += sum_t V[t, f] * P[t, label]; k-step s' pairs tokens {4q + s'}
+            // O^T[f, label] += sum_t V[t, f] * P[t, label]; k-step sp pairs tokens {4q + sp}.  sp outermost:
+            // consecutive MFMAs hit different accumulators (the 16x16x4 form has a 40-cycle dependent latency)
             const float* vp = Vs + (16 * u + 4 * lq) * FP + lr;
 #pragma unroll
-            for (int j = 0; j < NFT; ++j) {
+            for (int sp = 0; sp < 4; ++sp) {
 #pragma unroll
-                for (int sp = 0; sp < 4; ++sp) acc[j] = mfma16(vp[sp * FP + 16 * j], p[sp], acc[j]);
+                for (int j = 0; j < NFT; ++j) acc[j] = mfma16(vp[sp * FP + 16 * j], p[sp], acc[j]);
             }
         }
     }
@@ -214,6 +271,9 @@ __device__ __forceinline__ void flush_tiles(const f32x4 (&tiles)[NTILES], float*
 }
 
 #define BWD_BL 16  // labels per pipeline step
+#ifndef GZ_ABL
+#define GZ_ABL 0  // diagnostic builds only (tools/ablate_bwd.py): bit 0 no dQ, 1 no dK/dV MFMAs, 2 no RNG, 3 no streaming, 4 no epilogue, 5 no S/dP
+#endif
 
 struct AttnBwdArgs {
     const float* dO;
@@ -232,39 +292,55 @@ struct AttnBwdArgs {
     float scale;
 };
 
-// LDS plan of the backward kernel, shared by the kernel and its launcher
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// LDS plan of the backward kernel, shared by the kernel and its launcher.  Every MFMA operand that comes from LDS is
+// laid out so that ONE ds_read_b128 feeds four MFMAs (a narrow ds_read_b32 per MFMA left the matrix pipe waiting on
+// LDS latency: 15 % of peak).  The streamed 16-label tiles therefore exist in two images each:
+//   "p" (row = label, columns permuted so that a lane's successive k-steps are contiguous):
+//        elem(l, c) at l*RS + (c & 3)*KS + (c >> 2)      -> A operand of S = Q.K^T and dP = dO.V^T   (k runs over c)
+//   "T" (row = column c of the tile, 16 labels + pad contiguous):
+//        elem(l, c) at c*RST + l                          -> A operand of dK^T += Q^T.dS, dV^T += dO^T.Pd (k runs over l)
 template <int ES, int NFT, int NW>
 struct BwdLds {
-    static constexpr int NET = (4 * ES + 15) / 16;                        // 16-wide tiles over E
-    static constexpr int EPQ = (16 * NET + 2 > 4 * ES + 2) ? 16 * NET + 2 : 4 * ES + 2;  // Q / K row stride (2*odd)
-    static constexpr int FP = 16 * NFT + 2;                               // dO row stride (2*odd)
-    static constexpr int SCR = 17;
+    static constexpr int NET = (4 * ES + 15) / 16;  // 16-wide tiles over E
+    static constexpr int ESP = (ES + 3) / 4 * 4;    // k-steps over E, padded to whole b128 reads
+    static constexpr int FS = 4 * NFT;              // k-steps over F (already a multiple of 4)
+    static constexpr int RSQ = 4 * ESP + 4;         // row stride of the permuted Q / K images
+    static constexpr int RSO = 4 * FS + 4;          // row stride of the permuted dO image
+    static constexpr int RST = 20;                  // row stride of the transposed images (16 labels + 4)
     static constexpr int DQW = 16 * NET;
-    static constexpr int oQ = 0;                                          // [2][16][EPQ]
-    static constexpr int odO = oQ + 2 * BWD_BL * EPQ;                     // [2][16][FP]
-    static constexpr int oLse = odO + 2 * BWD_BL * FP;                    // [2][16]
-    static constexpr int oDel = oLse + 2 * BWD_BL;                        // [2][16]
-    static constexpr int oScr = oDel + 2 * BWD_BL;                        // [NW][16][17]
-    static constexpr int odQ = oScr + NW * 16 * SCR;                      // [2][16][DQW]
-    static constexpr int oK = odQ + 2 * BWD_BL * DQW;                     // [NW*16][EPQ]  this workgroup's keys
-    static constexpr int total = oK + NW * 16 * EPQ;
-    static constexpr int stage = NW * 16 * BWD_STW;                       // epilogue staging (aliases the front)
+    static constexpr int oQp = 0;                        // [16][RSQ]
+    static constexpr int oQT = oQp + BWD_BL * RSQ;       // [16*NET][RST]
+    static constexpr int oOp = oQT + 16 * NET * RST;     // [16][RSO]
+    static constexpr int oOT = oOp + BWD_BL * RSO;       // [16*NFT][RST]
+    static constexpr int oLse = oOT + 16 * NFT * RST;    // [16]
+    static constexpr int oDel = oLse + BWD_BL;           // [16]
+    static constexpr int RSD = 16 * NW + 4;              // row stride of the dS image (tokens permuted like "p")
+    static constexpr int oDS = oDel + BWD_BL;            // [2][16][RSD]   dS of the workgroup's tokens, double-buffered
+    static constexpr int odQ = oDS + 2 * BWD_BL * RSD;   // [16][DQW]      dQ tile of the previous step (plain stores)
+    static constexpr int oKp = odQ + BWD_BL * DQW;       // [NW*16][RSQ]   this workgroup's keys, permuted image
+    static constexpr int total = oKp + NW * 16 * RSQ;
+    static constexpr int stage = NW * 16 * BWD_STW;      // epilogue staging (aliases the front)
     static constexpr int floats = total > stage ? total : stage;
 };
 
 template <int ES, int NFT, int NW>
 __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) {
     using P = BwdLds<ES, NFT, NW>;
-    constexpr int NET = P::NET, FS = 4 * NFT, EPQ = P::EPQ, FP = P::FP, SCR = P::SCR, DQW = P::DQW;
+    constexpr int NET = P::NET, ESP = P::ESP, FS = P::FS, RSQ = P::RSQ, RSO = P::RSO, RST = P::RST, DQW = P::DQW;
+    constexpr int RSD = P::RSD;
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
-    float* Qs = sm + P::oQ;
-    float* dOs = sm + P::odO;
+    float* Qp = sm + P::oQp;
+    float* QT = sm + P::oQT;
+    float* Op = sm + P::oOp;
+    float* OT = sm + P::oOT;
     float* lse_s = sm + P::oLse;
     float* del_s = sm + P::oDel;
     float* dQs = sm + P::odQ;
-    float* Kt = sm + P::oK;
+    float* Kp = sm + P::oKp;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -295,21 +371,33 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     const float* PXb = a.PX + (long long)b * a.Tp * a.E;
     const float* Xb = a.X + (long long)b * a.Tp * a.F;
 
-    // zero all of LDS once: pad columns of the staged tiles must never hold NaN bit patterns
+    // zero all of LDS once: pad words of the staged images must never hold NaN bit patterns
     for (int i = tid; i < P::floats; i += NT) sm[i] = 0.f;
     __syncthreads();
-    // this workgroup's keys: Kt[token][e] (B operand of S = Q.K^T and of dQ += dS.K)
-    for (int i = tid; i < NW * 16 * 4 * ES; i += NT) {
-        const int r = i / (4 * ES), c = i % (4 * ES);
-        const int t = tt * 16 * NW + r;
-        if (t < a.Tp && c < a.E) Kt[r * EPQ + c] = PXb[(long long)t * a.E + c];
-    }
-    // values stay in registers: B operand of dP = dO.V^T :  V[tok][4s + lq]
-    float vT[FS];
+    // this workgroup's keys, permuted image Kp[token][(e&3)*ESP + (e>>2)]; batched straight-line loads
+    {
+        constexpr int KPT = (NW * 16 * 4 * ES + NT - 1) / NT;
+        float kk[KPT];
 #pragma unroll
-    for (int s = 0; s < FS; ++s) {
-        int f = 4 * s + lq;
-        vT[s] = (tok_ok && f < a.F) ? Xb[(long long)tok * a.F + f] : 0.f;
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
+            kk[i] = PXb[(long long)min(tt * 16 * NW + r, a.Tp - 1) * a.E + min(c, a.E - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
+            if (r < NW * 16 && tt * 16 * NW + r < a.Tp && c < a.E) Kp[r * RSQ + (c & 3) * ESP + (c >> 2)] = kk[i];
+        }
+    }
+    // values stay in registers: B operand of dP = dO.V^T :  V[tok][4s + lq]  (mask by multiply: loads stay unconditional)
+    float vT[FS];
+    {
+        const float* vrow = Xb + (long long)min(tok, a.Tp - 1) * a.F;
+#pragma unroll
+        for (int s = 0; s < FS; ++s) {
+            const int f = 4 * s + lq;
+            vT[s] = vrow[min(f, a.F - 1)] * ((tok_ok && f < a.F) ? 1.f : 0.f);
+        }
     }
 
     f32x4 dKT[NET], dVT[NFT];
@@ -324,150 +412,204 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     // staging: thread -> (row, col) pieces of the 16 x E and 16 x F tiles
     constexpr int QPT = (BWD_BL * 4 * ES + NT - 1) / NT;
     constexpr int OPT = (BWD_BL * 16 * NFT + NT - 1) / NT;
+    constexpr int DQF = (BWD_BL * DQW + NT - 1) / NT;
     float pq[QPT], po[OPT], plse = 0.f, pdel = 0.f;
+    // Straight-line loads from CLAMPED addresses, no validity selects: a `cond ? load : 0` makes hipcc branch around
+    // each load and wait vmcnt(0) inside the branch (one exposed L2 round trip per element, every step).  Rows past
+    // L are neutralised through lse = +inf (P = 0, so dS = Pd = 0 whatever finite Q / dO row was read); columns past
+    // E / F meet zero key / value pads, or produce accumulator rows that are never stored.
     auto prefetch = [&](int step) {
         const int l0 = step * BWD_BL;
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
-            int l = l0 + r;
-            pq[i] = (r < BWD_BL && l < a.L && c < a.E) ? a.Q[(long long)l * a.E + c] : 0.f;
+            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
+            pq[i] = a.Q[(long long)min(l0 + r, a.L - 1) * a.E + min(c, a.E - 1)];
         }
 #pragma unroll
         for (int i = 0; i < OPT; ++i) {
-            int idx = tid + NT * i, r = idx / (16 * NFT), c = idx % (16 * NFT);
-            int l = l0 + r;
-            po[i] = (r < BWD_BL && l < a.L && c < a.F) ? a.dO[((long long)b * a.L + l) * a.F + c] : 0.f;
+            const int idx = tid + NT * i, r = idx / (16 * NFT), c = idx % (16 * NFT);
+            po[i] = a.dO[((long long)b * a.L + min(l0 + r, a.L - 1)) * a.F + min(c, a.F - 1)];
         }
-        if (tid < BWD_BL) {
-            int l = l0 + tid;
-            plse = (l < a.L) ? a.LSE[(long long)b * a.L + l] : INFINITY;  // +inf -> P = 0 for labels past L
-            pdel = (l < a.L) ? a.DELTA[(long long)b * a.L + l] : 0.f;
+        {
+            const int l = l0 + (tid & (BWD_BL - 1));
+            const long long o = (long long)b * a.L + min(l, a.L - 1);
+            plse = a.LSE[o] + ((l < a.L) ? 0.f : INFINITY);  // +inf -> P = 0 for labels past L
+            pdel = a.DELTA[o];
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&]() {  // registers -> both LDS images of each tile
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
-            int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
-            if (r < BWD_BL) Qs[(buf * BWD_BL + r) * EPQ + c] = pq[i];
+            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
+            if (r < BWD_BL) {
+                Qp[r * RSQ + (c & 3) * ESP + (c >> 2)] = pq[i];
+                QT[c * RST + r] = pq[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < OPT; ++i) {
-            int idx = tid + NT * i, r = idx / (16 * NFT), c = idx % (16 * NFT);
-            if (r < BWD_BL) dOs[(buf * BWD_BL + r) * FP + c] = po[i];
+            const int idx = tid + NT * i, r = idx / (16 * NFT), c = idx % (16 * NFT);
+            if (r < BWD_BL) {
+                Op[r * RSO + (c & 3) * FS + (c >> 2)] = po[i];
+                OT[c * RST + r] = po[i];
+            }
         }
         if (tid < BWD_BL) {
-            lse_s[buf * BWD_BL + tid] = plse;
-            del_s[buf * BWD_BL + tid] = pdel;
+            lse_s[tid] = plse;
+            del_s[tid] = pdel;
         }
     };
 
-    if (step_beg < step_end) {
-        prefetch(step_beg);
-        commit(0);
+    // Each workgroup starts its label sweep at a different step: workgroups that run together would otherwise all
+    // add their dQ partials into the SAME 16 rows at the same time, and same-address float atomics serialise at the
+    // memory side (an order of magnitude below the 1.3 TB/s spread-out atomic rate).
+    const int nsteps = step_end - step_beg;
+    const int rot = nsteps > 0 ? (int)(((unsigned)(tt * 7 + b * 13) * 2654435761u >> 8) % (unsigned)nsteps) : 0;
+    auto step_of = [&](int i) { int s = i + rot; return step_beg + (s >= nsteps ? s - nsteps : s); };
+    if (nsteps > 0) {
+        prefetch(step_of(0));
+        commit();
     }
     __syncthreads();
 
-    float* myscr = sm + P::oScr + wave * 16 * SCR;
-    const float* Kw = Kt + (wave * 16) * EPQ;  // this wave's 16 keys
-    for (int step = step_beg; step < step_end; ++step) {
-        const int buf = (step - step_beg) & 1;
-        const int l0 = step * BWD_BL;
-        const bool more = step + 1 < step_end;
-        if (more) prefetch(step + 1);
-        // flush the dQ partials of the previous step (other buffer) with row-contiguous float atomics; every thread
-        // clears exactly the words it read (pad columns only ever receive zeros), so no extra barrier is needed
-        if (step > step_beg) {
-            float* src = dQs + (buf ^ 1) * BWD_BL * DQW;
-            const int lprev = l0 - BWD_BL;
-            for (int i = tid; i < BWD_BL * a.E; i += NT) {
-                int r = i / a.E, c = i % a.E;
-                const float v = src[r * DQW + c];
-                src[r * DQW + c] = 0.f;
-                if (lprev + r < a.L) atomicAdd(a.dQ + (long long)(lprev + r) * a.E + c, v);
+    float* dSs = sm + P::oDS;
+    const float* Kw = Kp + (wave * 16) * RSQ;  // this wave's 16 keys
+    // dQ[l, e] = sum_tok dS[l, tok] K[tok, e] sums over the tokens of ALL waves.  The waves exchange dS through one
+    // LDS tile and wave w owns output columns e in [16w, 16w+16) over the whole 16*NW-token K range: no cross-wave
+    // reduction (LDS float atomics ran at < 1 lane/clk/CU and cost 3/4 of the kernel).  The product for step i runs
+    // inside step i+1 (double-buffered dS tile), so it needs no barrier of its own.
+    auto dq_tile = [&](int buf_prev) {
+        const float* dsp = dSs + buf_prev * BWD_BL * RSD;
+        for (int j = wave; j < NET; j += NW) {
+            f32x4 q0 = f32x4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
+            const f32x4v* ap = reinterpret_cast<const f32x4v*>(dsp + lr * RSD + lq * 4 * NW);  // dS[label lr][tok 4s+lq]
+            // K[tok = 4s + lq][e = 16j + lr] in the permuted image: column (lr & 3)*ESP + 4j + (lr >> 2)
+            const float* kq = Kp + lq * RSQ + (lr & 3) * ESP + 4 * j + (lr >> 2);
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                const f32x4v av = ap[g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float kv = kq[(4 * (4 * g + i)) * RSQ];
+                    if (i & 1) q1 = mfma16(av[i], kv, q1);
+                    else q0 = mfma16(av[i], kv, q0);
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dQs[(4 * lq + r) * DQW + 16 * j + lr] = q0[r] + q1[r];
         }
-        const float* Qt = Qs + buf * BWD_BL * EPQ;
-        const float* dOt = dOs + buf * BWD_BL * FP;
-        // S tile (rows = labels l0 + 4lq + r, cols = tokens) and dP tile, two accumulators each (40-cycle MFMA latency)
+    };
+    auto dq_flush = [&](int l0p) {  // row-contiguous float atomics; fixed trip count, unrolled (no vmcnt(0) drain)
+#pragma unroll
+        for (int i = 0; i < DQF; ++i) {
+            const int idx = tid + NT * i;
+            const int r = idx / DQW, c = idx % DQW;
+            if (idx < BWD_BL * DQW && c < a.E && l0p + r < a.L)
+                atomicAdd(a.dQ + (long long)(l0p + r) * a.E + c, dQs[idx]);
+        }
+    };
+    int l0_prev = 0;
+    for (int it = 0; it < nsteps; ++it) {
+        const int step = step_of(it);
+        const int l0 = step * BWD_BL;
+        const bool more = it + 1 < nsteps;
+        if (more && !(GZ_ABL & 8)) prefetch(step_of(it + 1));  // in flight during the MFMAs below
+        // S tile (rows = labels l0 + 4lq + r, cols = tokens) and dP tile; two accumulators each (40-cycle latency)
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-        {
-            const float* qp = Qt + lr * EPQ + lq;
-            const float* kp = Kw + lr * EPQ + lq;
+        if (!(GZ_ABL & 32)) {
+            const f32x4v* qp = reinterpret_cast<const f32x4v*>(Qp + lr * RSQ + lq * ESP);
+            const f32x4v* kp = reinterpret_cast<const f32x4v*>(Kw + lr * RSQ + lq * ESP);
 #pragma unroll
-            for (int s = 0; s < ES; ++s) {
-                if (s & 1) s1 = mfma16(qp[4 * s], kp[4 * s], s1);
-                else s0 = mfma16(qp[4 * s], kp[4 * s], s0);
+            for (int g = 0; g < ESP / 4; ++g) {
+                const f32x4v qa = qp[g], ka = kp[g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (4 * g + i < ES) {
+                        if (i & 1) s1 = mfma16(qa[i], ka[i], s1);
+                        else s0 = mfma16(qa[i], ka[i], s0);
+                    }
+                }
             }
-            const float* op = dOt + lr * FP + lq;
+            const f32x4v* op = reinterpret_cast<const f32x4v*>(Op + lr * RSO + lq * FS);
 #pragma unroll
-            for (int s = 0; s < FS; ++s) {
-                if (s & 1) d1 = mfma16(op[4 * s], vT[s], d1);
-                else d0 = mfma16(op[4 * s], vT[s], d0);
+            for (int g = 0; g < FS / 4; ++g) {
+                const f32x4v oa = op[g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i & 1) d1 = mfma16(oa[i], vT[4 * g + i], d1);
+                    else d0 = mfma16(oa[i], vT[4 * g + i], d0);
+                }
             }
         }
         float pd[4], ds[4];
+        {
+            const f32x4v lse4 = *reinterpret_cast<const f32x4v*>(lse_s + 4 * lq);
+            const f32x4v del4 = *reinterpret_cast<const f32x4v*>(del_s + 4 * lq);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int lrow = 4 * lq + r;
-            const float lse = lse_s[buf * BWD_BL + lrow];
-            const float del = del_s[buf * BWD_BL + lrow];
-            float p = tok_ok ? __expf(s0[r] + s1[r] - lse) : 0.f;
-            float dsc = 1.f;
-            if (a.thresh) {
-                const uint32_t key = gz_mix32(seedmix ^ ((rowbase + (uint32_t)(l0 + lrow)) * 0x9E3779B1u));
-                dsc = (gz_u32(key, (uint32_t)tok) >= a.thresh) ? a.scale : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                float p = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
+                float dsc = 1.f;
+                if (a.thresh && !(GZ_ABL & 4)) {
+                    const uint32_t key = gz_mix32(seedmix ^ ((rowbase + (uint32_t)(l0 + 4 * lq + r)) * 0x9E3779B1u));
+                    dsc = (gz_u32(key, (uint32_t)tok) >= a.thresh) ? a.scale : 0.f;
+                }
+                pd[r] = p * dsc;
+                ds[r] = p * ((d0[r] + d1[r]) * dsc - del4[r]);
             }
-            pd[r] = p * dsc;
-            ds[r] = p * ((d0[r] + d1[r]) * dsc - del);
+        }
+        // publish this wave's dS block (label 4lq + r, token 16*wave + lr) into the step's dS tile
+        {
+            float* dw = dSs + (it & 1) * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * 4 * NW + 4 * wave + (lr >> 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dw[r * RSD] = ds[r];
         }
         // dV^T[f, tok] += sum_l dO[l, f] Pd[l, tok] ;  dK^T[e, tok] += sum_l Q[l, e] dS[l, tok]
-        {
-            const float* op = dOt + (4 * lq) * FP + lr;
+        // one b128 read = the four k-steps of one accumulator tile; two tiles in flight alternate (independent MFMAs)
+        if (!(GZ_ABL & 2)) {
+            const float* op = OT + lr * RST + 4 * lq;
 #pragma unroll
-            for (int j = 0; j < NFT; ++j)
+            for (int j = 0; j < NFT; j += 2) {
+                const f32x4v a0 = *reinterpret_cast<const f32x4v*>(op + (16 * j) * RST);
+                f32x4v a1 = a0;
+                if (j + 1 < NFT) a1 = *reinterpret_cast<const f32x4v*>(op + (16 * (j + 1)) * RST);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) dVT[j] = mfma16(op[s * FP + 16 * j], pd[s], dVT[j]);
-            const float* qp = Qt + (4 * lq) * EPQ + lr;
+                for (int s = 0; s < 4; ++s) {
+                    dVT[j] = mfma16(a0[s], pd[s], dVT[j]);
+                    if (j + 1 < NFT) dVT[j + 1] = mfma16(a1[s], pd[s], dVT[j + 1]);
+                }
+            }
+            const float* qp = QT + lr * RST + 4 * lq;
 #pragma unroll
-            for (int j = 0; j < NET; ++j)
+            for (int j = 0; j < NET; j += 2) {
+                const f32x4v a0 = *reinterpret_cast<const f32x4v*>(qp + (16 * j) * RST);
+                f32x4v a1 = a0;
+                if (j + 1 < NET) a1 = *reinterpret_cast<const f32x4v*>(qp + (16 * (j + 1)) * RST);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) dKT[j] = mfma16(qp[s * EPQ + 16 * j], ds[s], dKT[j]);
-        }
-        // dQ[l, e] += sum_tok dS[l, tok] K[tok, e]: transpose this wave's dS through its private LDS scratch
-#pragma unroll
-        for (int r = 0; r < 4; ++r) myscr[(4 * lq + r) * SCR + lr] = ds[r];
-        {
-            float aT[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) aT[s] = myscr[lr * SCR + 4 * s + lq];
-            float* dst = dQs + buf * BWD_BL * DQW + (4 * lq) * DQW + lr;
-            const float* kq = Kw + lq * EPQ + lr;  // K[tok0 + 4s + lq][16j + lr]
-#pragma unroll
-            for (int j = 0; j < NET; ++j) {
-                f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) q = mfma16(aT[s], kq[4 * s * EPQ + 16 * j], q);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dst + r * DQW + 16 * j, q[r]);  // ds_add_f32 across the waves
+                for (int s = 0; s < 4; ++s) {
+                    dKT[j] = mfma16(a0[s], ds[s], dKT[j]);
+                    if (j + 1 < NET) dKT[j + 1] = mfma16(a1[s], ds[s], dKT[j + 1]);
+                }
             }
         }
-        if (more) commit(buf ^ 1);
+        // dQ of the PREVIOUS step (its dS tile was completed before that step's first barrier)
+        if (it > 0 && !(GZ_ABL & 1)) dq_tile((it - 1) & 1);
+        __syncthreads();  // tiles fully consumed; previous step's dQ tile and this step's dS tile complete
+        if (it > 0 && !(GZ_ABL & 1)) dq_flush(l0_prev);
+        if (more && !(GZ_ABL & 8)) commit();
+        l0_prev = l0;
         __syncthreads();
     }
-    // flush the last step's dQ partials
-    if (step_beg < step_end) {
-        const int buf = (step_end - 1 - step_beg) & 1;
-        const float* src = dQs + buf * BWD_BL * DQW;
-        const int l0 = (step_end - 1) * BWD_BL;
-        for (int i = tid; i < BWD_BL * a.E; i += NT) {
-            int r = i / a.E, c = i % a.E;
-            if (l0 + r < a.L) atomicAdd(a.dQ + (long long)(l0 + r) * a.E + c, src[r * DQW + c]);
-        }
+    if (nsteps > 0 && !(GZ_ABL & 1)) {  // dQ of the last step
+        dq_tile((nsteps - 1) & 1);
+        __syncthreads();
+        dq_flush(l0_prev);
     }
     __syncthreads();
+    if (GZ_ABL & 2) {  // keep the accumulators' producers alive in ablation builds
+        dKT[0][0] += 0.f;
+    }
     // epilogue: dK^T / dV^T tiles -> token-major rows through per-wave LDS staging, row-contiguous atomics
-    {
+    if (!(GZ_ABL & 16)) {
         float* st = sm + wave * 16 * BWD_STW;
         flush_tiles<NET>(dKT, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
         flush_tiles<NFT>(dVT, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
@@ -479,7 +621,11 @@ static int launch_fwd(const AttnFwdArgs& a, hipStream_t st) {
     constexpr int EP = 4 * ES + 2, FP = 16 * NFT + 4;
     size_t smem = (size_t)FWD_BT * (EP + FP) * 4;
     const int nLT = cdiv(a.L, 16 * FWD_WAVES);
-    hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT>), dim3(a.B * nLT), dim3(FWD_WAVES * 64), smem, st, a);
+    const dim3 grid(a.B * nLT), block(FWD_WAVES * 64);
+    if ((a.E & 3) == 0 && (a.F & 3) == 0)
+        hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 4>), grid, block, smem, st, a);
+    else
+        hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 1>), grid, block, smem, st, a);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libgzsl_hip.so')
+LIB_PATH = os.environ.get('GZSL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgzsl_hip.so')  # env: diagnostic builds
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 EINVAL = 1001
