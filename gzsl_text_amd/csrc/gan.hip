@@ -67,13 +67,18 @@ __global__ void gp_dw2_kernel(const float* __restrict__ dv, const float* __restr
     atomicAdd(dw2 + col, acc);
 }
 
+// lrelu_in: `a` holds PRE-activations; LeakyReLU(0.2) is applied on the fly (the activated tensor is never stored)
 __global__ void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
-                              float* __restrict__ out, int Bg, int H) {
+                              float* __restrict__ out, int Bg, int H, int lrelu_in) {
     const int lane = threadIdx.x & 63;
     int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     for (; row < Bg; row += gridDim.x * (blockDim.x >> 6)) {
         float s = 0.f;
-        for (int j = lane; j < H; j += 64) s += a[(long long)row * H + j] * w[j];
+        for (int j = lane; j < H; j += 64) {
+            float x = a[(long long)row * H + j];
+            if (lrelu_in) x = x > 0.f ? x : 0.2f * x;
+            s += x * w[j];
+        }
         s = wave_sum(s);
         if (lane == 0) out[row] = s + (bias ? bias[0] : 0.f);
     }
@@ -89,7 +94,7 @@ __global__ void weighted_sum_kernel(const float* __restrict__ x, const float* __
 
 __global__ void rowdot_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w,
                                   const float* __restrict__ act, float* __restrict__ da, float* dw, float* db, int Bg,
-                                  int H, int rows_per_block) {
+                                  int H, int rows_per_block, int lrelu_in) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(Bg, r0 + rows_per_block);
@@ -97,9 +102,9 @@ __global__ void rowdot_bwd_kernel(const float* __restrict__ dout, const float* _
         const float wj = w[col];
         float acc = 0.f;
         for (int r = r0; r < r1; ++r) {
-            const float a = act[(long long)r * H + col];
+            float a = act[(long long)r * H + col];
             const float d = dout[r];
-            acc += d * a;
+            acc += d * ((lrelu_in && a <= 0.f) ? 0.2f * a : a);
             if (da) da[(long long)r * H + col] = d * wj * (a > 0.f ? 1.f : 0.2f);
         }
         if (dw) atomicAdd(dw + col, acc);
@@ -201,9 +206,9 @@ extern "C" int gzsl_gp_dw2(const float* dv, const float* s, float* dw2, int Bg, 
 }
 
 extern "C" int gzsl_rowdot(const float* a, const float* w, const float* bias, float* out, int Bg, int H,
-                           void* stream) {
+                           int lrelu_in, void* stream) {
     if (Bg <= 0) return 0;
-    hipLaunchKernelGGL(rowdot_kernel, dim3(ew_blocks(Bg, 4)), dim3(256), 0, ST, a, w, bias, out, Bg, H);
+    hipLaunchKernelGGL(rowdot_kernel, dim3(ew_blocks(Bg, 4)), dim3(256), 0, ST, a, w, bias, out, Bg, H, lrelu_in);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
@@ -218,11 +223,11 @@ extern "C" int gzsl_weighted_sum(const float* x, const float* w, float scale, fl
 }
 
 extern "C" int gzsl_rowdot_bwd(const float* dout, const float* w, const float* act, float* da, float* dw, float* db,
-                               int Bg, int H, void* stream) {
+                               int Bg, int H, int lrelu_in, void* stream) {
     if (Bg <= 0) return 0;
     const int rpb = 64;
     hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(cdiv(H, 256), cdiv(Bg, rpb)), dim3(256), 0, ST, dout, w, act, da, dw, db,
-                       Bg, H, rpb);
+                       Bg, H, rpb, lrelu_in);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

@@ -56,9 +56,9 @@ _PROTOS = {
     'gzsl_gp_slope_v': [c_void_p] * 4 + [c_int, c_int, c_void_p],
     'gzsl_gp_rownorm': [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     'gzsl_gp_dw2': [c_void_p] * 3 + [c_int, c_int, c_void_p],
-    'gzsl_rowdot': [c_void_p] * 4 + [c_int, c_int, c_void_p],
+    'gzsl_rowdot': [c_void_p] * 4 + [c_int, c_int, c_int, c_void_p],
     'gzsl_weighted_sum': [c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p],
-    'gzsl_rowdot_bwd': [c_void_p] * 6 + [c_int, c_int, c_void_p],
+    'gzsl_rowdot_bwd': [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p],
     'gzsl_keyword_ce': [c_void_p] * 5 + [c_int] * 3 + [c_void_p],
 }
 

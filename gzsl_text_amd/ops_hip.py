@@ -294,9 +294,9 @@ class HipOps:
     def gp_dw2_(self, dv, s, dw2):
         call('gzsl_gp_dw2', ptr(dv), ptr(s), ptr(dw2), dv.shape[0], dv.shape[1])
 
-    def rowdot(self, a, w, bias):
+    def rowdot(self, a, w, bias, lrelu_in=False):
         out = torch.empty(a.shape[0], dtype=torch.float32, device=a.device)
-        call('gzsl_rowdot', ptr(a), ptr(w), ptr(bias), ptr(out), a.shape[0], a.shape[1])
+        call('gzsl_rowdot', ptr(a), ptr(w), ptr(bias), ptr(out), a.shape[0], a.shape[1], int(lrelu_in))
         return out
 
     def weighted_sum(self, x, w, scale):
@@ -304,9 +304,10 @@ class HipOps:
         call('gzsl_weighted_sum', ptr(x), ptr(w), float(scale), ptr(out), x.numel())
         return out
 
-    def rowdot_bwd(self, dout, w, act, dw, db, need_da=True):
+    def rowdot_bwd(self, dout, w, act, dw, db, need_da=True, lrelu_in=False):
         da = torch.empty_like(act) if need_da else None
-        call('gzsl_rowdot_bwd', ptr(dout), ptr(w), ptr(act), ptr(da), ptr(dw), ptr(db), act.shape[0], act.shape[1])
+        call('gzsl_rowdot_bwd', ptr(dout), ptr(w), ptr(act), ptr(da), ptr(dw), ptr(db), act.shape[0], act.shape[1],
+             int(lrelu_in))
         return da
 
     def keyword_ce_(self, logits, kw_idx, kw_mask, w):

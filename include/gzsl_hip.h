@@ -125,13 +125,15 @@ int gzsl_gp_slope_v(const float* h, const float* w2, float* v, float* s, int Bg,
 int gzsl_gp_rownorm(float* g, float* gp, int Bg, int D, float lam, void* stream);
 /* dw2[j] += sum_b dv[b,j]*s[b,j] */
 int gzsl_gp_dw2(const float* dv, const float* s, float* dw2, int Bg, int H, void* stream);
-/* out[b] = dot(a[b,:], w) + bias0 (critic fc2 with one output, generative_module.py:60,67-68); bias may be NULL */
-int gzsl_rowdot(const float* a, const float* w, const float* bias, float* out, int Bg, int H, void* stream);
+/* out[b] = dot(act(a[b,:]), w) + bias0 (critic fc2 with one output, generative_module.py:60,67-68); bias may be NULL.
+ * lrelu_in != 0: `a` holds pre-activations and LeakyReLU(0.2) is applied on the fly. */
+int gzsl_rowdot(const float* a, const float* w, const float* bias, float* out, int Bg, int H, int lrelu_in,
+                void* stream);
 /* *out += sum_b x[b] * w[b] * scale (critic means, train_gan.py:244,252,300); w may be NULL */
 int gzsl_weighted_sum(const float* x, const float* w, float scale, float* out, int n, void* stream);
 /* da[b,j] = dout[b] * w[j] * slope(act[b,j]);  dw[j] += sum_b dout[b]*act[b,j];  db += sum_b dout[b]  (fc2 backward, one output) */
 int gzsl_rowdot_bwd(const float* dout, const float* w, const float* act, float* da, float* dw, float* db, int Bg,
-                    int H, void* stream);
+                    int H, int lrelu_in, void* stream);
 /* decoder_module.py:39-59 soft-target cross-entropy over the keyword vocabulary: loss_b = -sum_v log_softmax(logits)[b,v]*t[b,v],
  * t = normalised mask scattered by assignment (last duplicate wins).  Writes loss_b and, in place, dlogits = w_b*(softmax*sum(t) - t). */
 int gzsl_keyword_ce(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* w, float* loss_b, int Bg,

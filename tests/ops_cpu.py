@@ -232,16 +232,18 @@ class CpuOps:
     def gp_dw2_(self, dv, s, dw2):
         dw2 += (dv * s).sum(0)
 
-    def rowdot(self, a, w, bias):
+    def rowdot(self, a, w, bias, lrelu_in=False):
+        if lrelu_in:
+            a = F.leaky_relu(a, 0.2)
         r = a @ w
         return r + bias[0] if bias is not None else r
 
     def weighted_sum(self, x, w, scale):
         return ((x * w).sum() if w is not None else x.sum()) * scale
 
-    def rowdot_bwd(self, dout, w, act, dw, db, need_da=True):
+    def rowdot_bwd(self, dout, w, act, dw, db, need_da=True, lrelu_in=False):
         if dw is not None:
-            dw += dout @ act
+            dw += dout @ (F.leaky_relu(act, 0.2) if lrelu_in else act)
         if db is not None:
             db += dout.sum()
         if need_da:

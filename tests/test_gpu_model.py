@@ -56,3 +56,10 @@ def test_gan_variant_matches_reference_golden():
         helpers.close(model.output_fc.weight.grad, g[f'ff_dfc{step}'], 1e-4, 1e-6, f'forward_final grad {step}')
         opt.step()
         helpers.close(model.output_fc.weight, g[f'ff_fc_after{step}'], 1e-5, 1e-6, f'AdamW params after {step}')
+
+
+@pytest.mark.parametrize('name', ['gan_step_tiny', 'gan_step_medium'])
+def test_wgan_gp_step_matches_reference_golden(name):
+    from gzsl_text_amd.ops_hip import HipOps
+    from tests.gan_checks import run_gan_step_check
+    run_gan_step_check(name, HipOps(), DEV)
