@@ -89,7 +89,7 @@ def cpu_baseline(case, args):
     """Oracle (numpy restatement) timed on the host: one note of the same workload, fwd+bwd, all labels."""
     from oracle import base_model as om
     d = case['dims']
-    nb = 1
+    nb = 8
     margin = om.class_margin_from_count(case['target_count'])
     x, y, mask = case['x'][:nb], case['y'][:nb], case['mask'][:nb]
     t0 = time.perf_counter()
@@ -97,7 +97,7 @@ def cpu_baseline(case, args):
     dt = time.perf_counter() - t0
     cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
     return {'value': nb / dt, 'unit': 'notes/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{nb} note of the same workload (T={d["T"]}, L={d["L"]}, N={d["N"]}), fwd+bwd incl. label '
+            'sample': f'{nb} notes of the same workload (T={d["T"]}, L={d["L"]}, N={d["N"]}), fwd+bwd incl. label '
                       f'encoder, numpy fp32 oracle, BLAS threads={cores}, {dt:.1f} s'}
 
 
