@@ -59,9 +59,8 @@ class KernelTimer:
         self.ops = ops
         self.events = {'attn_fwd': [], 'attn_bwd': []}
         self.enabled = False
-        self._fwd, self._bwd = ops.attn_fwd, ops.attn_bwd
-        ops.attn_fwd = self._wrap('attn_fwd', self._fwd)
-        ops.attn_bwd = self._wrap_bwd(self._bwd)
+        ops.attn_fwd = self._wrap('attn_fwd', ops.attn_fwd)
+        ops.attn_bwd_main = self._wrap('attn_bwd', ops.attn_bwd_main)  # the label_attn_bwd launch alone
 
     def _wrap(self, name, fn):
         def inner(*a, **k):
@@ -74,11 +73,6 @@ class KernelTimer:
             self.events[name].append((e0, e1))
             return r
         return inner
-
-    def _wrap_bwd(self, fn):
-        # attn_bwd = delta kernel + the main kernel: time only the main kernel by timing the whole op and the delta
-        # launch is ~1 % of it (HBM-bound 2 x B*L*F*4 bytes); reported as the op time
-        return self._wrap('attn_bwd', fn)
 
     def mean_ms(self, name):
         ev = self.events[name]

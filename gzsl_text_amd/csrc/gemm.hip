@@ -15,14 +15,17 @@
 //
 // Tiling: 256 threads = 4 waves; each wave owns WTM x WTN tiles of v_mfma_f32_16x16x4_f32 (exact fp32, 64
 // FLOP/clk/SIMD - the only fp32 matrix rate gfx950 has; there is no xf32).  BK = 32, operands staged through LDS
-// with row stride 34 floats (34 = 2 mod 32 -> the 16 rows x 2 k-lanes of one ds_read_b32 hit 32 distinct banks).
-// Global loads for tile t+1 are issued into registers before tile t's MFMAs and written to LDS after them.
+// with the k columns of each row PERMUTED: logical k = 4s + q sits at column q*8 + s, so the four k-steps 4g..4g+3
+// of lane quarter q are 16 contiguous bytes and ONE ds_read_b128 feeds four MFMAs (a ds_read_b32 per MFMA left the
+// matrix pipe waiting on LDS latency).  Global loads for tile t+1 are issued into registers before tile t's MFMAs
+// and written to LDS after them.
 #include "common.h"
 #include "../../include/gzsl_hip.h"
 
 #define BK 32
-#define LDK 34
+#define LDK 36  // row stride: multiple of 4 floats so every fragment read is one aligned ds_read_b128
 #define NTHREADS 256
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <int ROWS, bool KCONTIG>
 struct Idx {
@@ -132,20 +135,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GzslGemm g) {
         for (int i = 0; i < NA; ++i) {
             int r, c;
             Idx<BM, A_KC>::rc(tid, i, r, c);
-            As[r * LDK + c] = ra[i];
+            As[r * LDK + (c & 3) * 8 + (c >> 2)] = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             int r, c;
             Idx<BN, B_KC>::rc(tid, i, r, c);
-            Bs[r * LDK + c] = rb[i];
+            Bs[r * LDK + (c & 3) * 8 + (c >> 2)] = rb[i];
         }
     };
 
     const int lr = lane & 15;
     const int lq = lane >> 4;
-    const float* Aw = As + (wm * WTM * 16 + lr) * LDK + lq;
-    const float* Bw = Bs + (wn * WTN * 16 + lr) * LDK + lq;
+    const float* Aw = As + (wm * WTM * 16 + lr) * LDK + lq * 8;
+    const float* Bw = Bs + (wn * WTN * 16 + lr) * LDK + lq * 8;
 
     if (kbeg < kend) {
         load_tile(kbeg);
@@ -156,16 +159,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GzslGemm g) {
         const bool more = (k0 + BK) < kend;
         if (more) load_tile(k0 + BK);
 #pragma unroll
-        for (int s = 0; s < BK / 4; ++s) {
-            float a[WTM], b[WTN];
+        for (int g4 = 0; g4 < BK / 16; ++g4) {
+            f32x4v a[WTM], b[WTN];
 #pragma unroll
-            for (int i = 0; i < WTM; ++i) a[i] = Aw[i * 16 * LDK + 4 * s];
+            for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const f32x4v*>(Aw + i * 16 * LDK + 4 * g4);
 #pragma unroll
-            for (int j = 0; j < WTN; ++j) b[j] = Bw[j * 16 * LDK + 4 * s];
+            for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const f32x4v*>(Bw + j * 16 * LDK + 4 * g4);
 #pragma unroll
-            for (int i = 0; i < WTM; ++i)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
         }
         __syncthreads();
         if (more) store_tile();

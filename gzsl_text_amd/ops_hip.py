@@ -236,9 +236,14 @@ class HipOps:
             nsplit = 1
             while wgs * nsplit < 1024 and nsplit * 2 * 16 <= L:
                 nsplit *= 2
+        self.attn_bwd_main(dO, PX, X, Q, lse, delta, dPX, dX, dQ, l_offset, L_total, nsplit, seed, p)
+
+    def attn_bwd_main(self, dO, PX, X, Q, lse, delta, dPX, dX, dQ, l_offset, L_total, nsplit, seed, p):
+        """The label_attn_bwd kernel alone (bench.py times this launch for the roofline line)."""
+        B, Tp, E = PX.shape
         th, sc = drop_params(p)
         call('gzsl_label_attn_bwd', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
-             ptr(dQ), B, Tp, E, F_, L, l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc)
+             ptr(dQ), B, Tp, E, X.shape[2], Q.shape[0], l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc)
 
     def logits_fwd(self, direct, clf):
         B, L, D = direct.shape
