@@ -13,52 +13,225 @@
 // split_k > 1: blockIdx.z owns a K range and stores alpha * partial to C + z * slab_stride (no bias/act);
 //   gzsl_splitk_reduce sums the slabs in a fixed order (bitwise reproducible, no float atomics).
 //
-// Tiling: 256 threads = 4 waves; each wave owns WTM x WTN tiles of v_mfma_f32_16x16x4_f32 (exact fp32, 64
-// FLOP/clk/SIMD - the only fp32 matrix rate gfx950 has; there is no xf32).  BK = 32, operands staged through LDS
-// with the k columns of each row PERMUTED: logical k = 4s + q sits at column q*8 + s, so the four k-steps 4g..4g+3
-// of lane quarter q are 16 contiguous bytes and ONE ds_read_b128 feeds four MFMAs (a ds_read_b32 per MFMA left the
-// matrix pipe waiting on LDS latency).  Global loads for tile t+1 are issued into registers before tile t's MFMAs
-// and written to LDS after them.
+// Design (round-1 v3):
+//   * 256 threads = 4 waves stacked along M, each wave owns WTM x WTN tiles of v_mfma_f32_16x16x4_f32 (exact fp32,
+//     64 FLOP/clk/SIMD: the only fp32 matrix rate gfx950 has; tools/mfma_peak.hip measures 156.3 TFLOP/s sustained).
+//     Tiles are small (64 or 128 rows x 112/128/208 columns) and register use is bounded so that 2-3 workgroups
+//     share a CU: their barriers and global-load waits overlap each other's MFMA phases, and the many small tiles
+//     keep the last round of the grid short.
+//   * BK = 16, two LDS buffers, ONE barrier per k-tile.  Tile t+1 travels
+//     global -> registers while tile t's MFMAs issue, then registers -> the other LDS buffer.
+//   * Every operand moves as 16-byte vectors end to end.  An operand that is contiguous along k ("KC") is staged
+//     as [row][k] and a lane's ds_read_b128 holds its k values for FOUR consecutive MFMA steps (k = 16*group +
+//     4*quarter + step: the order of the k sum is free as long as A and B agree).  An operand that is contiguous
+//     along its rows ("RC": weight-gradient products, W in data-gradient products) is staged as [k][row] and tile i
+//     of a lane covers row 64*(i/4) + 4*lane + i%4, so that one ds_read_b128 holds one k step of FOUR tiles.  No
+//     transposes through LDS, no scalar LDS traffic, no bank conflicts (see kc_off).
+//   * Bounds / window / k-range predicates never branch around a load: the address is clamped to the operand base
+//     and the loaded bits are ANDed with a 0/~0 mask, so all loads of a tile stay in flight together.
+//   * Operands whose strides or extents are not multiples of 4 floats use the same layouts with scalar loads
+//     (VEC = false instantiations).
 #include "common.h"
 #include "../../include/gzsl_hip.h"
 
-#define BK 32
-#define LDK 36  // row stride: multiple of 4 floats so every fragment read is one aligned ds_read_b128
+#ifndef BK
+#define BK 16  // 16: 64-byte rows, 3 workgroups per CU; 32: full 128-byte lines, 2 per CU (measured equal within 4 %)
+#endif
+#define LDK BK  // [row][k] images are unpadded; see kc_off
 #define NTHREADS 256
-typedef float f32x4v __attribute__((ext_vector_type(4)));
+#ifndef GZ_GEMM_ABL
+#define GZ_GEMM_ABL 0  // timing experiments only (tools/ablate_gemm.sh): 1 no loads, 2 no LDS stores, 4 no barrier, 8 no MFMA
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int ROWS, bool KCONTIG>
-struct Idx {
-    // element i of this thread inside a ROWS x BK tile -> (row r, k column c); lanes run along the contiguous dim
-    __device__ static __forceinline__ void rc(int tid, int i, int& r, int& c) {
-        int idx = tid + NTHREADS * i;
-        if (KCONTIG) {
-            r = idx >> 5;
-            c = idx & 31;
-        } else {
-            r = idx % ROWS;
-            c = idx / ROWS;
+struct Operand {
+    const float* p;
+    long long mbs, kbs;  // strides between row batches / k batches
+    int rows, mb, sm, sk, shift;
+    unsigned span;
+};
+
+// [row][k] image: the 16-byte chunk c (k = 4c..4c+3) of row r lives at chunk c ^ swz(r).  ds_read_b128 serves the lane
+// groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) with banks (a/4) mod 64 (MI355X_MICROARCH.md, LDS): a lane of
+// quarter q reads chunk 4*kgroup + q of row 16*tile + (lane & 15), and with these XORs each group's 16 lanes cover
+// all 64 banks exactly once (4 LDS cycles, the minimum); the 8-lane groups of ds_write_b128 are conflict-free too.
+__device__ __forceinline__ int kc_off(int r, int c) {
+#if BK == 32
+    return r * LDK + 4 * (c ^ ((r >> 1) & 7));  // 128-byte rows: two rows per bank row
+#else
+    return r * LDK + 4 * (c ^ ((r >> 2) & 2));  // 64-byte rows: four rows per bank row
+#endif
+}
+
+__device__ __forceinline__ float mask_bits(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
+
+// Global -> register -> LDS mover for one operand tile of ROWS rows x BK k.  RPAD = row count of the [k][row] image.
+template <int ROWS, int RPAD, bool RC, bool VEC>
+struct Mover {
+    static constexpr int TOTAL = ROWS * BK / 4;  // 16-byte slots in the tile
+    static constexpr int NS = (TOTAL + NTHREADS - 1) / NTHREADS;
+    static constexpr int NR = (RC && !VEC) ? 4 : 1;  // distinct rows per slot that need their own state
+    long long rb[NS][NR];
+    int orow[NS][NR];
+    int kc[NS], lds_off[NS];
+    struct Tile {  // one tile's worth of this thread's slots, in flight or landed
+        unsigned msk[NS][VEC ? 1 : 4];
+        f32x4 v[NS];
+    };
+
+    // dump: float offset (from the operand's image in an LDS buffer) of this thread's 16-byte parking place: a thread
+    // without a slot stores there, so that the stores need no branch
+    __device__ __forceinline__ void init(const Operand& op, int tid, int row0, int dump) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int s = tid + NTHREADS * i;
+            bool st = s < TOTAL;
+            int sc = st ? s : TOTAL - 1;
+            int r;
+            if (!RC) {
+                r = sc / (BK / 4);
+                kc[i] = 4 * (sc % (BK / 4));
+                lds_off[i] = st ? kc_off(r, kc[i] >> 2) : dump;
+            } else {
+                kc[i] = sc / (ROWS / 4);
+                r = 4 * (sc % (ROWS / 4));
+                lds_off[i] = st ? kc[i] * RPAD + r : dump;
+            }
+#pragma unroll
+            for (int e = 0; e < NR; ++e) {
+                int row = row0 + r + e;
+                bool valid = row < op.rows;
+                int rowc = valid ? row : 0;
+                int mbi = rowc / op.mb;
+                int mi = rowc - mbi * op.mb;
+                rb[i][e] = (long long)mbi * op.mbs;
+                // a row outside the operand gets an offset that no k can bring back into [0, span)
+                orow[i][e] = valid ? mi * op.sm + op.shift : (int)0x80000000;
+            }
+        }
+    }
+
+    // k0: first k of the tile; (kb0, ki0): its batch decomposition
+    __device__ __forceinline__ void load(const Operand& op, int k0, int kb0, int ki0, int kend, int k_inner,
+                                         Tile& d) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (VEC) {
+                int ki = ki0 + kc[i], kb = kb0;
+                if (ki >= k_inner) {
+                    ki -= k_inner;
+                    kb += 1;
+                }
+                int o = orow[i][0] + ki * op.sk;
+                bool ok = (k0 + kc[i] < kend) && ((unsigned)o < op.span);
+                unsigned m = ok ? 0xFFFFFFFFu : 0u;
+                long long off = (rb[i][0] + (long long)kb * op.kbs + o) & (long long)(int)m;  // no branch
+                d.v[i] = *reinterpret_cast<const f32x4*>(op.p + off);
+                d.msk[i][0] = m;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int er = RC ? e : 0;
+                    int kk = kc[i] + (RC ? 0 : e);
+                    int ki = ki0 + kk, kb = kb0;
+                    if (ki >= k_inner) {
+                        ki -= k_inner;
+                        kb += 1;
+                    }
+                    int o = orow[i][er] + ki * op.sk;
+                    bool ok = (k0 + kk < kend) && ((unsigned)o < op.span);
+                    unsigned m = ok ? 0xFFFFFFFFu : 0u;
+                    long long off = (rb[i][er] + (long long)kb * op.kbs + o) & (long long)(int)m;
+                    d.v[i][e] = op.p[off];
+                    d.msk[i][e] = m;
+                }
+            }
+        }
+    }
+
+    // the mask is applied here, after the tile's MFMAs, so that nothing waits on a load before it has to
+    __device__ __forceinline__ void store(float* buf, const Tile& d) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            f32x4 t = d.v[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = mask_bits(t[e], d.msk[i][VEC ? 0 : e]);
+            *reinterpret_cast<f32x4*>(buf + lds_off[i]) = t;
         }
     }
 };
 
-template <int WTM, int WTN, int WGM, int WGN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GzslGemm g) {
-    constexpr int BM = 16 * WTM * WGM;
-    constexpr int BN = 16 * WTN * WGN;
-    constexpr int NA = BM / 8;  // elements of the A tile per thread
-    constexpr int NB = BN / 8;
+// tile / lane -> row of an operand block of NTOT tiles.  [row][k] images use the natural order.  [k][row] images
+// are read as vectors along the rows, so tiles are grouped: a group of 4 tiles covers 64 rows with tile e of lane l
+// on row 4*l + e; what is left of NTOT forms a group of 2 (row 2*l + e) and / or a single natural tile.
+template <bool RC, int NTOT>
+__device__ __forceinline__ int tile_row(int tile, int l) {
+    if (!RC) return 16 * tile + l;
+    constexpr int G4 = NTOT / 4 * 4;
+    constexpr bool HAS2 = (NTOT - G4) >= 2;
+    if (tile < G4) return 64 * (tile >> 2) + 4 * l + (tile & 3);
+    if (HAS2 && tile < G4 + 2) return 16 * G4 + 2 * l + (tile - G4);
+    return 16 * (G4 + (HAS2 ? 2 : 0)) + l;
+}
+
+// Fragments f[tile][step] of NT tiles for the four k steps of the lane's quarter in k group g (k = 16g + 4*lq + step).
+// Either NT == NTOT (the whole block, t0 == 0) or NT in {1, 2} and NTOT is a multiple of 4 (a wave's share of A).
+template <int NT, int NTOT, int RPAD, bool RC>
+__device__ __forceinline__ void read_frags(const float* buf, int g, int t0, int lr, int lq, float (&f)[NT][4]) {
+    if (!RC) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(buf + kc_off(16 * (t0 + i) + lr, 4 * g + lq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[i][j] = t[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* row = buf + (16 * g + 4 * lq + j) * RPAD;
+            if (NT != NTOT && NT == 1) {
+                f[0][j] = row[64 * (t0 >> 2) + 4 * lr + (t0 & 3)];
+            } else if (NT != NTOT && NT == 2) {
+                f32x2 t = *reinterpret_cast<const f32x2*>(row + 64 * (t0 >> 2) + 4 * lr + (t0 & 3));
+                f[0][j] = t[0];
+                f[1][j] = t[1];
+            } else {
+                constexpr int G4 = NT / 4 * 4;
+                constexpr bool HAS2 = (NT - G4) >= 2;
+                constexpr bool HAS1 = ((NT - G4) & 1) != 0;
+#pragma unroll
+                for (int gi = 0; gi < NT / 4; ++gi) {
+                    f32x4 t = *reinterpret_cast<const f32x4*>(row + 64 * gi + 4 * lr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[4 * gi + e][j] = t[e];
+                }
+                if (HAS2) {
+                    f32x2 t = *reinterpret_cast<const f32x2*>(row + 16 * G4 + 2 * lr);
+                    f[G4][j] = t[0];
+                    f[G4 + 1][j] = t[1];
+                }
+                if (HAS1) f[NT - 1][j] = row[16 * (G4 + (HAS2 ? 2 : 0)) + lr];
+            }
+        }
+    }
+}
+
+template <int WTM, int WTN, bool A_RC, bool B_RC, bool VEC>
+__global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2) : (BK == 16 ? 2 : 1))) void gemm_f32_kernel(GzslGemm g) {
+    constexpr int BM = 64 * WTM;
+    constexpr int BN = 16 * WTN;
+    constexpr int BNP = BN;  // [k][row] image of B: rows in natural order, BN is a multiple of 16 (bank rule)
+    constexpr int ASZ = A_RC ? BK * BM : BM * LDK;
+    constexpr int BSZ = B_RC ? BK * BNP : BN * LDK;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* As = reinterpret_cast<float*>(smem_raw);
-    float* Bs = As + BM * LDK;
-    long long* a_base = reinterpret_cast<long long*>(Bs + BN * LDK);  // (BM+BN)*34*4 B is a multiple of 8
-    int* a_o = reinterpret_cast<int*>(a_base + BM);
+    float* lds = reinterpret_cast<float*>(smem_raw);  // [2][ASZ + BSZ + 4 * NTHREADS (parking area)]
+    constexpr int BUF = ASZ + BSZ + 4 * NTHREADS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WGN;
-    const int wn = wave % WGN;
+    const int lr = lane & 15;
+    const int lq = lane >> 4;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int m0 = (blockIdx.x / tiles_n) * BM;
     const int n0 = (blockIdx.x % tiles_n) * BN;
@@ -69,20 +242,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GzslGemm g) {
         kend = min(g.K, kbeg + g.k_per_split);
     }
 
-    for (int r = tid; r < BM; r += NTHREADS) {
-        int m = m0 + r;
-        long long base = 0;
-        int o = 0;
-        if (m < g.M) {
-            int mb = m / g.a_mb;
-            int mi = m - mb * g.a_mb;
-            base = (long long)mb * g.a_mbs;
-            o = mi * g.a_sm + g.a_shift;
-        }
-        a_base[r] = base;
-        a_o[r] = o;
-    }
-    __syncthreads();
+    Operand oa{g.A, g.a_mbs, g.a_kbs, g.M, g.a_mb, g.a_sm, g.a_sk, g.a_shift, g.a_span};
+    Operand ob{g.B, 0ll, g.b_kbs, g.N, 0x7FFFFFFF, g.b_sn, g.b_sk, 0, 0x7FFFFFFFu};
+    Mover<BM, BM, A_RC, VEC> ma;
+    Mover<BN, BNP, B_RC, VEC> mb;
+    ma.init(oa, tid, m0, ASZ + BSZ + 4 * tid);
+    mb.init(ob, tid, n0, BSZ + 4 * tid);
 
     f32x4 acc[WTM][WTN];
 #pragma unroll
@@ -90,91 +255,61 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GzslGemm g) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float ra[NA], rb[NB];
-    const bool kbatched = g.k_inner < g.K;
-
-    auto load_tile = [&](int k0) {
-        int kb0 = 0, ki0 = k0;
-        if (kbatched) {
-            kb0 = k0 / g.k_inner;
-            ki0 = k0 - kb0 * g.k_inner;
+    const int k_inner = g.k_inner;
+    const int ntile = (kend - kbeg + BK - 1) / BK;
+    // (kb, ki): batch decomposition of the first k of the next tile to fetch; k_next: that k
+    int k_next = kbeg;
+    int kb0 = kbeg / k_inner;
+    int ki0 = kbeg - kb0 * k_inner;
+    typename Mover<BM, BM, A_RC, VEC>::Tile ga;
+    typename Mover<BN, BNP, B_RC, VEC>::Tile gb;
+    auto fetch = [&]() {
+        // past kend every slot is masked and its address clamped: the surplus fetch of the last iteration is harmless
+        if (!(GZ_GEMM_ABL & 1)) {
+            ma.load(oa, k_next, kb0, ki0, kend, k_inner, ga);
+            mb.load(ob, k_next, kb0, ki0, kend, k_inner, gb);
         }
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int r, c;
-            Idx<BM, A_KC>::rc(tid, i, r, c);
-            int kb = kb0, ki = ki0 + c;
-            if (ki >= g.k_inner) {
-                ki -= g.k_inner;
-                kb += 1;
-            }
-            int o = a_o[r] + ki * g.a_sk;
-            bool ok = (m0 + r < g.M) && (k0 + c < kend) && ((unsigned)o < g.a_span);
-            float v = 0.f;
-            if (ok) v = g.A[a_base[r] + (long long)kb * g.a_kbs + o];
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            int r, c;
-            Idx<BN, B_KC>::rc(tid, i, r, c);
-            int kb = kb0, ki = ki0 + c;
-            if (ki >= g.k_inner) {
-                ki -= g.k_inner;
-                kb += 1;
-            }
-            int n = n0 + r;
-            bool ok = (n < g.N) && (k0 + c < kend);
-            float v = 0.f;
-            if (ok) v = g.B[(long long)kb * g.b_kbs + (long long)ki * g.b_sk + (long long)n * g.b_sn];
-            rb[i] = v;
+        k_next += BK;
+        ki0 += BK;
+        if (ki0 >= k_inner) {
+            ki0 -= k_inner;
+            kb0 += 1;
         }
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int r, c;
-            Idx<BM, A_KC>::rc(tid, i, r, c);
-            As[r * LDK + (c & 3) * 8 + (c >> 2)] = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            int r, c;
-            Idx<BN, B_KC>::rc(tid, i, r, c);
-            Bs[r * LDK + (c & 3) * 8 + (c >> 2)] = rb[i];
-        }
-    };
-
-    const int lr = lane & 15;
-    const int lq = lane >> 4;
-    const float* Aw = As + (wm * WTM * 16 + lr) * LDK + lq * 8;
-    const float* Bw = Bs + (wn * WTN * 16 + lr) * LDK + lq * 8;
-
-    if (kbeg < kend) {
-        load_tile(kbeg);
-        store_tile();
-    }
+    fetch();
+    ma.store(lds, ga);
+    mb.store(lds + ASZ, gb);
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = (k0 + BK) < kend;
-        if (more) load_tile(k0 + BK);
+    int cur = 0;
+    for (int t = 0; t < ntile; ++t) {
+        fetch();                            // tile t+1 -> registers
+        __builtin_amdgcn_sched_barrier(0);  // every load is in flight before tile t's MFMAs start
+        const float* abuf = lds + cur * BUF;
 #pragma unroll
-        for (int g4 = 0; g4 < BK / 16; ++g4) {
-            f32x4v a[WTM], b[WTN];
+        for (int kg = 0; kg < BK / 16; ++kg) {
+            if (kg > 0 && kbeg + t * BK + 16 * kg >= kend) break;  // K tail: nothing but zeros in this k group
+            float fa[WTM][4], fb[WTN][4];
+            read_frags<WTM, 4 * WTM, BM, A_RC>(abuf, kg, wave * WTM, lr, lq, fa);
+            read_frags<WTN, WTN, BNP, B_RC>(abuf + ASZ, kg, 0, lr, lq, fb);
+            if (!(GZ_GEMM_ABL & 8)) {
 #pragma unroll
-            for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const f32x4v*>(Aw + i * 16 * LDK + 4 * g4);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const f32x4v*>(Bw + j * 16 * LDK + 4 * g4);
+                    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WTN; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+                        for (int n = 0; n < WTN; ++n) acc[i][n] = mfma16(fa[i][j], fb[n][j], acc[i][n]);
+            } else {
+                acc[0][0][0] += fa[0][0] + fb[0][0];
+            }
         }
-        __syncthreads();
-        if (more) store_tile();
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);  // ... and nothing waits on them until the MFMAs have issued
+        cur ^= 1;
+        float* nbuf = lds + cur * BUF;
+        if (!(GZ_GEMM_ABL & 2)) {
+            ma.store(nbuf, ga);
+            mb.store(nbuf + ASZ, gb);
+        }
+        if (!(GZ_GEMM_ABL & 4)) __syncthreads();
     }
 
     float* C = g.C + (g.split_k > 1 ? (long long)z * g.slab_stride : 0);
@@ -183,12 +318,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GzslGemm g) {
     for (int i = 0; i < WTM; ++i) {
 #pragma unroll
         for (int j = 0; j < WTN; ++j) {
-            int col = n0 + (wn * WTN + j) * 16 + lr;
+            int col = n0 + tile_row<B_RC, WTN>(j, lr);
             if (col >= g.N) continue;
             float bv = (!plain && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int row = m0 + (wm * WTM + i) * 16 + lq * 4 + r;
+                int row = m0 + tile_row<A_RC, 4 * WTM>(wave * WTM + i, lq * 4 + r);
                 if (row >= g.M) continue;
                 float v = g.alpha * acc[i][j][r];
                 long long off = (long long)row * g.ldc + col;
@@ -233,22 +368,60 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, long long s
     }
 }
 
-template <int WTM, int WTN, int WGM, int WGN>
+static bool mult4(long long v) { return (v & 3) == 0; }
+
+// Can every 16-byte slot of this operand be one aligned vector load that is wholly inside or wholly outside the
+// valid region?  rc: contiguous along rows (else along k).
+static bool vec_ok(const void* p, bool rc, int rows, int K, int mb, long long mbs, int sm, int sk, int shift,
+                   unsigned span, int k_inner, long long kbs) {
+    if (((uintptr_t)p & 15) != 0) return false;
+    const bool batched_rows = mb < rows, batched_k = k_inner < K;
+    if (!mult4(shift) || (span != 0x7FFFFFFFu && span != 0xFFFFFFFFu && !mult4(span))) return false;
+    if (batched_rows && !mult4(mbs)) return false;
+    if (batched_k && !mult4(kbs)) return false;
+    if (rc) {
+        if (sm != 1 || !mult4(rows)) return false;
+        if (K > 1 && !mult4(sk)) return false;
+        if (batched_rows && !mult4(mb)) return false;
+    } else {
+        if (sk != 1 || !mult4(K)) return false;
+        if (rows > 1 && !mult4(sm)) return false;
+        if (batched_k && !mult4(k_inner)) return false;
+    }
+    return true;
+}
+
+template <int WTM, int WTN>
 static int launch_cfg(const GzslGemm& g, hipStream_t st) {
-    constexpr int BM = 16 * WTM * WGM;
-    constexpr int BN = 16 * WTN * WGN;
-    size_t smem = (size_t)(BM + BN) * LDK * 4 + (size_t)BM * 12;
+    constexpr int BM = 64 * WTM;
+    constexpr int BN = 16 * WTN;
+    constexpr int BNP = BN;
+    // an operand is staged row-contiguous only when it is NOT contiguous along k
+    const bool arc = g.a_sk != 1 && g.a_sm == 1, brc = g.b_sk != 1 && g.b_sn == 1;
+    const bool vec = vec_ok(g.A, arc, g.M, g.K, g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span, g.k_inner, g.a_kbs) &&
+                     vec_ok(g.B, brc, g.N, g.K, 0x7FFFFFFF, 0, g.b_sn, g.b_sk, 0, 0xFFFFFFFFu, g.k_inner, g.b_kbs);
+    size_t smem = 2 * sizeof(float) * ((arc ? BK * BM : BM * LDK) + (brc ? BK * BNP : BN * LDK) + 4 * NTHREADS);
     dim3 grid(cdiv(g.M, BM) * cdiv(g.N, BN), 1, g.split_k > 1 ? g.split_k : 1);
-    const bool akc = g.a_sk == 1, bkc = g.b_sk == 1;
-#define GZ_LAUNCH(AK, BK_)                                                                                    \
-    hipLaunchKernelGGL((gemm_f32_kernel<WTM, WTN, WGM, WGN, AK, BK_>), grid, dim3(NTHREADS), smem, st, g)
-    if (akc && bkc) GZ_LAUNCH(true, true);
-    else if (akc && !bkc) GZ_LAUNCH(true, false);
-    else if (!akc && bkc) GZ_LAUNCH(false, true);
-    else GZ_LAUNCH(false, false);
+#define GZ_LAUNCH(AR, BR, V) \
+    hipLaunchKernelGGL((gemm_f32_kernel<WTM, WTN, AR, BR, V>), grid, dim3(NTHREADS), smem, st, g)
+#define GZ_PICK(V)                               \
+    do {                                         \
+        if (!arc && !brc) GZ_LAUNCH(false, false, V); \
+        else if (!arc && brc) GZ_LAUNCH(false, true, V); \
+        else if (arc && !brc) GZ_LAUNCH(true, false, V); \
+        else GZ_LAUNCH(true, true, V);           \
+    } while (0)
+    if (vec) GZ_PICK(true);
+    else GZ_PICK(false);
+#undef GZ_PICK
 #undef GZ_LAUNCH
     GZSL_CHECK_LAUNCH();
     return 0;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
 }
 
 extern "C" int gzsl_gemm(const GzslGemm* gp, void* stream) {
@@ -261,11 +434,22 @@ extern "C" int gzsl_gemm(const GzslGemm* gp, void* stream) {
         if (g.k_per_split <= 0 || g.k_per_split % BK != 0) return GZSL_EINVAL;
         if ((long long)g.k_per_split * g.split_k < g.K) return GZSL_EINVAL;
     }
-    // pick the tile whose padded N wastes least MFMA work (ties -> wider tile)
+    // tile width: the one whose padded N wastes least MFMA work (ties -> wider tile)
     const int pad128 = cdiv(g.N, 128) * 128, pad208 = cdiv(g.N, 208) * 208, pad112 = cdiv(g.N, 112) * 112;
-    if (pad208 < pad128 && pad208 <= pad112) return launch_cfg<2, 13, 4, 1>(g, st);
-    if (pad112 < pad128) return launch_cfg<2, 7, 4, 1>(g, st);
-    return launch_cfg<4, 4, 2, 2>(g, st);
+    const int wn = (pad208 < pad128 && pad208 <= pad112) ? 13 : (pad112 < pad128 ? 7 : 8);
+    // tile height: 128 rows once the grid is deep enough that the last round does not matter, else 64
+    static const int force_wtm = env_int("GZSL_GEMM_WTM", 0);
+    const long tiles64 = (long)cdiv(g.M, 64) * cdiv(g.N, 16 * wn) * (g.split_k > 1 ? g.split_k : 1);
+    int wtm = tiles64 >= 8192 ? 2 : 1;
+    if (force_wtm == 1 || force_wtm == 2) wtm = force_wtm;
+    if (wtm == 2) {
+        if (wn == 13) return launch_cfg<2, 13>(g, st);
+        if (wn == 7) return launch_cfg<2, 7>(g, st);
+        return launch_cfg<2, 8>(g, st);
+    }
+    if (wn == 13) return launch_cfg<1, 13>(g, st);
+    if (wn == 7) return launch_cfg<1, 7>(g, st);
+    return launch_cfg<1, 8>(g, st);
 }
 
 extern "C" int gzsl_splitk_reduce(const float* slab, long long slab_stride, int nsplit, float* out, int M, int N,

@@ -32,11 +32,13 @@ class HipOps:
     # ------------------------------------------------------------------------------------ GEMM plumbing
     @staticmethod
     def _split_policy(M, N, K):
-        """Split K when the output has too few tiles to fill 256 CUs (weight gradients: small MxN, huge K)."""
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        if tiles >= 128 or K < 2048:
+        """Split K when the output has too few 64-row tiles to fill 256 CUs x 3 workgroups (weight gradients: small
+        MxN, huge K).  Every split keeps at least 256 k (16 k-tiles) so that the prologue / epilogue stay amortised."""
+        bn = min((208, 112, 128), key=lambda w: ((N + w - 1) // w * w, -w))
+        tiles = ((M + 63) // 64) * ((N + bn - 1) // bn)
+        if tiles >= 384 or K < 1024:
             return 1, 0
-        split = min(max(1, 512 // tiles), max(1, K // 512))
+        split = min((768 + tiles - 1) // tiles, K // 256)
         if split <= 1:
             return 1, 0
         kper = ((K + split - 1) // split + 31) // 32 * 32
