@@ -52,6 +52,19 @@ def step_flops(d, B):
     return 3.0 * fwd
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this script).  FETCH_SIZE is doubled as MI355X_MICROARCH.md
+    prescribes for gfx950; returns None when no measurement is committed (bench.py cannot run the profiler itself)."""
+    fn = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(fn) as f:
+            d = json.load(f)[kernel]
+        return (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 class KernelTimer:
     """Wraps HipOps.attn_fwd / attn_bwd with event pairs on the launch stream (torch's current stream)."""
 
@@ -179,7 +192,10 @@ def main():
                                f'train mode (emb dropout .5, attn dropout .2), LDAM C=2, graph_encoder=gate',
                    'global_batch': B, 'seq_len': d['T'], 'parallelism': f'label-shard x{world}' if world > 1 else 'single'},
         'roofline': {'bound': 'mfma', 'kernel': 'label_attn_bwd_kernel', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                     'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
+                     'traffic': measured_traffic('label_attn_bwd_kernel') if world == 1 else None,
+                     'traffic_note': 'bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_pmc_traffic.json '
+                                     '(rocprofv3 PMC passes of this command at N=1; not re-measured in this run)',
                      'ms_per_launch': bwd_ms,
                      'algorithmic_flops_per_launch': 2 * fl_fwd,
                      'also': {'label_attn_fwd_kernel': {'ms_per_launch': fwd_ms,

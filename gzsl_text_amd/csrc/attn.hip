@@ -306,9 +306,17 @@ struct BwdLds {
     static constexpr int NET = (4 * ES + 15) / 16;  // 16-wide tiles over E
     static constexpr int ESP = (ES + 3) / 4 * 4;    // k-steps over E, padded to whole b128 reads
     static constexpr int FS = 4 * NFT;              // k-steps over F (already a multiple of 4)
-    static constexpr int RSQ = 4 * ESP + 4;         // row stride of the permuted Q / K images
-    static constexpr int RSO = 4 * FS + 4;          // row stride of the permuted dO image
-    static constexpr int RST = 20;                  // row stride of the transposed images (16 labels + 4)
+    // Strides: ds_read_b128 serves lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) with banks (a/4) mod 64
+    // (MI355X_MICROARCH.md, LDS).  A "p" image read at lr*RS + lq*KS + 4g is conflict-free (4 LDS cycles) when
+    // KS = 4 (mod 8) and RS = 4*KS + 8; a "T" image read at lr*RST + 4*lq when RST = 24.
+    static constexpr int ks(int steps) { return (steps % 8 == 4) ? steps : steps + 4; }
+    static constexpr int KSQ = ks(ESP);             // quarter stride of the permuted Q / K images
+    static constexpr int KSO = ks(FS);              // ... of the permuted dO image
+    static constexpr int KSD = ks(4 * NW);          // ... of the dS image
+    static constexpr int RSQ = 4 * KSQ + 8;         // row strides
+    static constexpr int RSO = 4 * KSO + 8;
+    static constexpr int RSD = 4 * KSD + 8;
+    static constexpr int RST = 24;                  // row stride of the transposed images (16 labels + 8)
     static constexpr int DQW = 16 * NET;
     static constexpr int oQp = 0;                        // [16][RSQ]
     static constexpr int oQT = oQp + BWD_BL * RSQ;       // [16*NET][RST]
@@ -316,7 +324,6 @@ struct BwdLds {
     static constexpr int oOT = oOp + BWD_BL * RSO;       // [16*NFT][RST]
     static constexpr int oLse = oOT + 16 * NFT * RST;    // [16]
     static constexpr int oDel = oLse + BWD_BL;           // [16]
-    static constexpr int RSD = 16 * NW + 4;              // row stride of the dS image (tokens permuted like "p")
     static constexpr int oDS = oDel + BWD_BL;            // [2][16][RSD]   dS of the workgroup's tokens, double-buffered
     static constexpr int odQ = oDS + 2 * BWD_BL * RSD;   // [16][DQW]      dQ tile of the previous step (plain stores)
     static constexpr int oKp = odQ + BWD_BL * DQW;       // [NW*16][RSQ]   this workgroup's keys, permuted image
@@ -329,7 +336,7 @@ template <int ES, int NFT, int NW>
 __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) {
     using P = BwdLds<ES, NFT, NW>;
     constexpr int NET = P::NET, ESP = P::ESP, FS = P::FS, RSQ = P::RSQ, RSO = P::RSO, RST = P::RST, DQW = P::DQW;
-    constexpr int RSD = P::RSD;
+    constexpr int RSD = P::RSD, KSQ = P::KSQ, KSO = P::KSO, KSD = P::KSD;
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
-            if (r < NW * 16 && tt * 16 * NW + r < a.Tp && c < a.E) Kp[r * RSQ + (c & 3) * ESP + (c >> 2)] = kk[i];
+            if (r < NW * 16 && tt * 16 * NW + r < a.Tp && c < a.E) Kp[r * RSQ + (c & 3) * KSQ + (c >> 2)] = kk[i];
         }
     }
     // values stay in registers: B operand of dP = dO.V^T :  V[tok][4s + lq]  (mask by multiply: loads stay unconditional)
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         for (int i = 0; i < QPT; ++i) {
             const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
             if (r < BWD_BL) {
-                Qp[r * RSQ + (c & 3) * ESP + (c >> 2)] = pq[i];
+                Qp[r * RSQ + (c & 3) * KSQ + (c >> 2)] = pq[i];
                 QT[c * RST + r] = pq[i];
             }
         }
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         for (int i = 0; i < OPT; ++i) {
             const int idx = tid + NT * i, r = idx / (16 * NFT), c = idx % (16 * NFT);
             if (r < BWD_BL) {
-                Op[r * RSO + (c & 3) * FS + (c >> 2)] = po[i];
+                Op[r * RSO + (c & 3) * KSO + (c >> 2)] = po[i];
                 OT[c * RST + r] = po[i];
             }
         }
@@ -482,9 +489,9 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         const float* dsp = dSs + buf_prev * BWD_BL * RSD;
         for (int j = wave; j < NET; j += NW) {
             f32x4 q0 = f32x4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
-            const f32x4v* ap = reinterpret_cast<const f32x4v*>(dsp + lr * RSD + lq * 4 * NW);  // dS[label lr][tok 4s+lq]
+            const f32x4v* ap = reinterpret_cast<const f32x4v*>(dsp + lr * RSD + lq * KSD);  // dS[label lr][tok 4s+lq]
             // K[tok = 4s + lq][e = 16j + lr] in the permuted image: column (lr & 3)*ESP + 4j + (lr >> 2)
-            const float* kq = Kp + lq * RSQ + (lr & 3) * ESP + 4 * j + (lr >> 2);
+            const float* kq = Kp + lq * RSQ + (lr & 3) * KSQ + 4 * j + (lr >> 2);
 #pragma unroll
             for (int g = 0; g < NW; ++g) {
                 const f32x4v av = ap[g];
@@ -517,8 +524,8 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         // S tile (rows = labels l0 + 4lq + r, cols = tokens) and dP tile; two accumulators each (40-cycle latency)
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
         if (!(GZ_ABL & 32)) {
-            const f32x4v* qp = reinterpret_cast<const f32x4v*>(Qp + lr * RSQ + lq * ESP);
-            const f32x4v* kp = reinterpret_cast<const f32x4v*>(Kw + lr * RSQ + lq * ESP);
+            const f32x4v* qp = reinterpret_cast<const f32x4v*>(Qp + lr * RSQ + lq * KSQ);
+            const f32x4v* kp = reinterpret_cast<const f32x4v*>(Kw + lr * RSQ + lq * KSQ);
 #pragma unroll
             for (int g = 0; g < ESP / 4; ++g) {
                 const f32x4v qa = qp[g], ka = kp[g];
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
                     }
                 }
             }
-            const f32x4v* op = reinterpret_cast<const f32x4v*>(Op + lr * RSO + lq * FS);
+            const f32x4v* op = reinterpret_cast<const f32x4v*>(Op + lr * RSO + lq * KSO);
 #pragma unroll
             for (int g = 0; g < FS / 4; ++g) {
                 const f32x4v oa = op[g];
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         }
         // publish this wave's dS block (label 4lq + r, token 16*wave + lr) into the step's dS tile
         {
-            float* dw = dSs + (it & 1) * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * 4 * NW + 4 * wave + (lr >> 2);
+            float* dw = dSs + (it & 1) * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * KSD + 4 * wave + (lr >> 2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) dw[r * RSD] = ds[r];
         }
