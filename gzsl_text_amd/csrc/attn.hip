@@ -298,38 +298,6 @@ __global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __r
     }
 }
 
-#define BWD_STW (16 * 7 + 1)  // staging row: up to 7 tiles (112 columns) per pass, odd stride
-
-// Accumulator tiles hold [column-of-output (4*lq + r), token (lr)]; write them to the wave's private LDS staging as
-// [token][column] and add whole token rows to global memory (256 contiguous bytes per wave-instruction: the shape
-// float atomics run at full rate in).  All indices are compile-time after unrolling (no scratch).
-template <int NTILES>
-__device__ __forceinline__ void flush_tiles(const f32x4 (&tiles)[NTILES], float* st, int lane, int tok0, int Tp,
-                                            int width, float* out, int ld) {
-    const int lr = lane & 15, lq = lane >> 4;
-#pragma unroll
-    for (int j0 = 0; j0 < NTILES; j0 += 7) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int nj = (NTILES - j0) < 7 ? (NTILES - j0) : 7;
-#pragma unroll
-        for (int jj = 0; jj < 7; ++jj) {
-            if (jj < nj) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[lr * BWD_STW + 16 * jj + 4 * lq + r] = tiles[j0 + jj < NTILES ? j0 + jj : 0][r];
-            }
-        }
-        for (int trow = 0; trow < 16; ++trow) {
-            const int t = tok0 + trow;
-            if (t >= Tp) break;
-            for (int c = lane; c < 16 * nj; c += 64) {
-                const int col = 16 * j0 + c;
-                if (col < width) atomicAdd(out + (long long)t * ld + col, st[trow * BWD_STW + c]);
-            }
-        }
-    }
-}
-
 #define BWD_BL 16  // labels per pipeline step
 #ifndef GZ_ABL
 #define GZ_ABL 0  // diagnostic builds only (tools/ablate_bwd.py): bit 0 no dQ, 1 no dK/dV MFMAs, 2 no RNG, 3 no streaming, 4 no epilogue, 5 no S/dP
@@ -352,60 +320,102 @@ struct AttnBwdArgs {
     float scale;
 };
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
+// column of accumulator tile j, lane row/col i, in a block of NT 16-wide tiles read as vectors along the columns:
+// groups of four tiles (col = 64*(j/4) + 4*i + j%4), then a pair (2*i + e), then a single natural tile.
+template <int NT>
+__device__ __forceinline__ int grp_col(int j, int i) {
+    constexpr int G4 = NT / 4 * 4;
+    constexpr bool HAS2 = (NT - G4) >= 2;
+    if (j < G4) return 64 * (j >> 2) + 4 * i + (j & 3);
+    if (HAS2 && j < G4 + 2) return 16 * G4 + 2 * i + (j - G4);
+    return 16 * (G4 + (HAS2 ? 2 : 0)) + i;
+}
 
-// LDS plan of the backward kernel, shared by the kernel and its launcher.  Every MFMA operand that comes from LDS is
-// laid out so that ONE ds_read_b128 feeds four MFMAs (a narrow ds_read_b32 per MFMA left the matrix pipe waiting on
-// LDS latency: 15 % of peak).  The streamed 16-label tiles therefore exist in two images each:
-//   "p" (row = label, columns permuted so that a lane's successive k-steps are contiguous):
-//        elem(l, c) at l*RS + (c & 3)*KS + (c >> 2)      -> A operand of S = Q.K^T and dP = dO.V^T   (k runs over c)
-//   "T" (row = column c of the tile, 16 labels + pad contiguous):
-//        elem(l, c) at c*RST + l                          -> A operand of dK^T += Q^T.dS, dV^T += dO^T.Pd (k runs over l)
+// LDS plan of the backward kernel, shared by the kernel and its launcher.
+//
+// The streamed 16-label tiles of Q [16][E] and dO [16][F] and the workgroup's keys K [16*NW][E] are kept as ONE natural
+// row-major image each, row stride RS = 16 * odd, with the 16-byte chunk index XORed with (row >> 1) & 3.  With that
+// stride and XOR both ways of reading an image are conflict-free ds_read_b128 (4 LDS cycles; lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32), banks (a/4) mod 64: MI355X_MICROARCH.md, LDS):
+//   "along k"   : lane (row lr, quarter lq) reads columns 16g + 4lq .. +3 = its k values for four consecutive MFMA steps
+//                 (A operands of S = Q.K^T and dP = dO.V^T, B operand K of S);
+//   "along rows": lane (lr, lq) reads row 4lq + r, columns grp_col(4jg.., lr) = the B operands of FOUR accumulator tiles
+//                 for k step r (dK += dS^T.Q and dV += Pd^T.dO, whose A operands dS / Pd are the S-tile registers).
+// Nothing is stored twice and nothing is transposed through LDS except dS, once per step, for dQ.
 template <int ES, int NFT, int NW>
 struct BwdLds {
     static constexpr int NET = (4 * ES + 15) / 16;  // 16-wide tiles over E
-    static constexpr int ESP = (ES + 3) / 4 * 4;    // k-steps over E, padded to whole b128 reads
-    static constexpr int FS = 4 * NFT;              // k-steps over F (already a multiple of 4)
-    // Strides: ds_read_b128 serves lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) with banks (a/4) mod 64
-    // (MI355X_MICROARCH.md, LDS).  A "p" image read at lr*RS + lq*KS + 4g is conflict-free (4 LDS cycles) when
-    // KS = 4 (mod 8) and RS = 4*KS + 8; a "T" image read at lr*RST + 4*lq when RST = 24.
+    static constexpr int NG = ES / 4;               // whole 4-step groups over e (S)
+    static constexpr int REM = ES % 4;              // leftover steps of S: e = 16*NG + 4*j + lq
+    static constexpr int FS = 4 * NFT;              // k steps over F (dP): whole groups, zero-padded values
+    static constexpr int rs(int w) { return ((w + 15) / 16) % 2 == 1 ? (w + 15) / 16 * 16 : (w + 15) / 16 * 16 + 16; }
+    static constexpr int RSQ = rs(16 * NET);        // row stride of the Q / K images
+    static constexpr int RSO = rs(16 * NFT);        // row stride of the dO image
     static constexpr int ks(int steps) { return (steps % 8 == 4) ? steps : steps + 4; }
-    static constexpr int KSQ = ks(ESP);             // quarter stride of the permuted Q / K images
-    static constexpr int KSO = ks(FS);              // ... of the permuted dO image
-    static constexpr int KSD = ks(4 * NW);          // ... of the dS image
-    static constexpr int RSQ = 4 * KSQ + 8;         // row strides
-    static constexpr int RSO = 4 * KSO + 8;
+    static constexpr int KSD = ks(4 * NW);          // dS image ("p" order: elem(l, tok) at l*RSD + (tok&3)*KSD + (tok>>2))
     static constexpr int RSD = 4 * KSD + 8;
-    static constexpr int RST = 24;                  // row stride of the transposed images (16 labels + 8)
     static constexpr int DQW = 16 * NET;
-    static constexpr int oQp = 0;                        // [16][RSQ]
-    static constexpr int oQT = oQp + BWD_BL * RSQ;       // [16*NET][RST]
-    static constexpr int oOp = oQT + 16 * NET * RST;     // [16][RSO]
-    static constexpr int oOT = oOp + BWD_BL * RSO;       // [16*NFT][RST]
-    static constexpr int oLse = oOT + 16 * NFT * RST;    // [16]
-    static constexpr int oDel = oLse + BWD_BL;           // [16]
-    static constexpr int oDS = oDel + BWD_BL;            // [2][16][RSD]   dS of the workgroup's tokens, double-buffered
-    static constexpr int odQ = oDS + 2 * BWD_BL * RSD;   // [16][DQW]      dQ tile of the previous step (plain stores)
-    static constexpr int oKp = odQ + BWD_BL * DQW;       // [NW*16][RSQ]   this workgroup's keys, permuted image
+    static constexpr int TQ = BWD_BL * RSQ, TO = BWD_BL * RSO, TSZ = TQ + TO;
+    static constexpr int oTiles = 0;                      // [2][TQ + TO]    Q and dO tiles, double-buffered
+    static constexpr int oAux = oTiles + 2 * TSZ;         // [2][48]         lse[16], delta[16], dropout row keys[16]
+    static constexpr int oDS = oAux + 2 * 48;             // [2][16][RSD]    dS of the workgroup's tokens
+    static constexpr int odQ = oDS + 2 * BWD_BL * RSD;    // [2][16][DQW]    dQ tiles awaiting their flush
+    static constexpr int oKp = odQ + 2 * BWD_BL * DQW;    // [NW*16][RSQ]    this workgroup's keys
     static constexpr int total = oKp + NW * 16 * RSQ;
-    static constexpr int stage = NW * 16 * BWD_STW;      // epilogue staging (aliases the front)
+    static constexpr int STW = 129;                       // epilogue staging row: 128 columns per pass, odd stride
+    static constexpr int stage = NW * 16 * STW;           // (aliases the front)
     static constexpr int floats = total > stage ? total : stage;
 };
 
-template <int ES, int NFT, int NW>
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 3; }
+// float offset of element (row, col) in a swizzled natural image of row stride RS
+__device__ __forceinline__ int img_off(int row, int col, int RS) { return row * RS + 4 * ((col >> 2) ^ swz(row)) + (col & 3); }
+
+// Accumulator tiles hold [token 4*lq + r][column grp_col(j, lr)].  Stage 128 columns at a time as [token][column] in the
+// wave's private LDS rows and add whole token rows to global memory (256 contiguous bytes per wave-instruction: the
+// shape float atomics run at full rate in).  All indices are compile-time after unrolling (no scratch).
+template <int NTILES, int STW>
+__device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NTILES], float* st, int lane, int tok0, int Tp,
+                                           int width, float* out, int ld) {
+    const int lr = lane & 15, lq = lane >> 4;
+    constexpr int NPASS = (16 * NTILES + 127) / 128;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+        for (int j = 0; j < NTILES; ++j) {
+            if (grp_col<NTILES>(j, 0) / 128 == ps) {
+                const int c = grp_col<NTILES>(j, lr) - 128 * ps;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[(4 * lq + r) * STW + c] = tiles[j][r];
+            }
+        }
+        const int ncol = min(128, 16 * NTILES - 128 * ps);
+        for (int trow = 0; trow < 16; ++trow) {
+            const int t = tok0 + trow;
+            if (t >= Tp) break;
+            for (int c = lane; c < ncol; c += 64) {
+                const int col = 128 * ps + c;
+                if (col < width) atomicAdd(out + (long long)t * ld + col, st[trow * STW + c]);
+            }
+        }
+    }
+}
+
+// G = floats per staging load (4 when E and F are multiples of 4)
+template <int ES, int NFT, int NW, int G>
 __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) {
     using P = BwdLds<ES, NFT, NW>;
-    constexpr int NET = P::NET, ESP = P::ESP, FS = P::FS, RSQ = P::RSQ, RSO = P::RSO, RST = P::RST, DQW = P::DQW;
-    constexpr int RSD = P::RSD, KSQ = P::KSQ, KSO = P::KSO, KSD = P::KSD;
+    constexpr int NET = P::NET, NG = P::NG, REM = P::REM, FS = P::FS, RSQ = P::RSQ, RSO = P::RSO, DQW = P::DQW;
+    constexpr int RSD = P::RSD, KSD = P::KSD, TQ = P::TQ, TSZ = P::TSZ;
     constexpr int NT = NW * 64;
+    constexpr int WQ = 4 * ES, WO = 16 * NFT;  // staged tile widths (compile-time; columns past E / F are clamped copies)
+    typedef float vecG __attribute__((ext_vector_type(G)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
-    float* Qp = sm + P::oQp;
-    float* QT = sm + P::oQT;
-    float* Op = sm + P::oOp;
-    float* OT = sm + P::oOT;
-    float* lse_s = sm + P::oLse;
-    float* del_s = sm + P::oDel;
+    float* tiles = sm + P::oTiles;
+    float* aux = sm + P::oAux;
+    float* dSs = sm + P::oDS;
     float* dQs = sm + P::odQ;
     float* Kp = sm + P::oKp;
 
@@ -441,89 +451,98 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     // zero all of LDS once: pad words of the staged images must never hold NaN bit patterns
     for (int i = tid; i < P::floats; i += NT) sm[i] = 0.f;
     __syncthreads();
-    // this workgroup's keys, permuted image Kp[token][(e&3)*ESP + (e>>2)]; batched straight-line loads
+    // this workgroup's keys; batched straight-line loads from clamped addresses, columns past E stay zero
     {
-        constexpr int KPT = (NW * 16 * 4 * ES + NT - 1) / NT;
+        constexpr int KPT = (NW * 16 * WQ + NT - 1) / NT;
         float kk[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
+            const int idx = tid + NT * i, r = idx / WQ, c = idx % WQ;
             kk[i] = PXb[(long long)min(tt * 16 * NW + r, a.Tp - 1) * a.E + min(c, a.E - 1)];
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
-            if (r < NW * 16 && tt * 16 * NW + r < a.Tp && c < a.E) Kp[r * RSQ + (c & 3) * KSQ + (c >> 2)] = kk[i];
+            const int idx = tid + NT * i, r = idx / WQ, c = idx % WQ;
+            if (r < NW * 16 && tt * 16 * NW + r < a.Tp && c < a.E) Kp[img_off(r, c, RSQ)] = kk[i];
         }
     }
-    // values stay in registers: B operand of dP = dO.V^T :  V[tok][4s + lq]  (mask by multiply: loads stay unconditional)
+    // values stay in registers, B operand of dP = dO.V^T in the k order of the "along k" reads:
+    //   vT[4g + j] = V[tok][16g + 4lq + j]   (mask by multiply: loads stay unconditional)
     float vT[FS];
     {
         const float* vrow = Xb + (long long)min(tok, a.Tp - 1) * a.F;
 #pragma unroll
         for (int s = 0; s < FS; ++s) {
-            const int f = 4 * s + lq;
+            const int f = 16 * (s >> 2) + 4 * lq + (s & 3);
             vT[s] = vrow[min(f, a.F - 1)] * ((tok_ok && f < a.F) ? 1.f : 0.f);
         }
     }
 
-    f32x4 dKT[NET], dVT[NFT];
+    f32x4 dK[NET], dV[NFT];  // [token 4lq + r][column grp_col(j, lr)]
 #pragma unroll
-    for (int j = 0; j < NET; ++j) dKT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NET; ++j) dK[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < NFT; ++j) dVT[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NFT; ++j) dV[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const uint32_t seedmix = gz_mix32(a.seed + GZSL_STREAM_ATTN * 0x632BE5ABu);
     const uint32_t rowbase = (uint32_t)b * (uint32_t)a.L_total + (uint32_t)a.l_offset;
+    const uint32_t tokmul = (uint32_t)tok * 0x85EBCA6Bu;  // gz_u32(key, tok) = mix32(key ^ tokmul)
 
-    // staging: thread -> (row, col) pieces of the 16 x E and 16 x F tiles
-    constexpr int QPT = (BWD_BL * 4 * ES + NT - 1) / NT;
-    constexpr int OPT = (BWD_BL * 16 * NFT + NT - 1) / NT;
+    // staging: thread -> G-float pieces of the 16 x WQ and 16 x WO tiles; offsets are loop-invariant
+    constexpr int QPT = (BWD_BL * WQ / G + NT - 1) / NT;
+    constexpr int OPT = (BWD_BL * WO / G + NT - 1) / NT;
     constexpr int DQF = (BWD_BL * DQW + NT - 1) / NT;
-    float pq[QPT], po[OPT], plse = 0.f, pdel = 0.f;
-    // Straight-line loads from CLAMPED addresses, no validity selects: a `cond ? load : 0` makes hipcc branch around
-    // each load and wait vmcnt(0) inside the branch (one exposed L2 round trip per element, every step).  Rows past
-    // L are neutralised through lse = +inf (P = 0, so dS = Pd = 0 whatever finite Q / dO row was read); columns past
-    // E / F meet zero key / value pads, or produce accumulator rows that are never stored.
+    int q_row[QPT], q_col[QPT], q_lds[QPT], o_row[OPT], o_col[OPT], o_lds[OPT];
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        const int f = (tid + NT * i) * G, r = f / WQ, c = f % WQ;
+        q_row[i] = r;
+        q_col[i] = min(c, a.E - G);
+        q_lds[i] = (r < BWD_BL) ? img_off(r, c, RSQ) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+        const int f = (tid + NT * i) * G, r = f / WO, c = f % WO;
+        o_row[i] = r;
+        o_col[i] = min(c, a.F - G);
+        o_lds[i] = (r < BWD_BL) ? img_off(r, c, RSO) : -1;
+    }
+    vecG pq[QPT], po[OPT];
+    float plse = 0.f, pdel = 0.f;
+    uint32_t pkey = 0;
+    // Straight-line loads from CLAMPED addresses, no validity selects (a `cond ? load : 0` makes hipcc branch around
+    // each load and wait vmcnt(0) inside the branch).  Rows past L are neutralised through lse = +inf (P = 0, so
+    // dS = Pd = 0 whatever finite Q / dO row was read); columns past E / F meet zero key / value pads, or produce
+    // accumulator columns that are never stored.
     auto prefetch = [&](int step) {
         const int l0 = step * BWD_BL;
 #pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
-            pq[i] = a.Q[(long long)min(l0 + r, a.L - 1) * a.E + min(c, a.E - 1)];
-        }
+        for (int i = 0; i < QPT; ++i)
+            pq[i] = *reinterpret_cast<const vecG*>(a.Q + (long long)min(l0 + q_row[i], a.L - 1) * a.E + q_col[i]);
 #pragma unroll
-        for (int i = 0; i < OPT; ++i) {
-            const int idx = tid + NT * i, r = idx / (16 * NFT), c = idx % (16 * NFT);
-            po[i] = a.dO[((long long)b * a.L + min(l0 + r, a.L - 1)) * a.F + min(c, a.F - 1)];
-        }
+        for (int i = 0; i < OPT; ++i)
+            po[i] = *reinterpret_cast<const vecG*>(a.dO + ((long long)b * a.L + min(l0 + o_row[i], a.L - 1)) * a.F + o_col[i]);
         {
             const int l = l0 + (tid & (BWD_BL - 1));
             const long long o = (long long)b * a.L + min(l, a.L - 1);
             plse = a.LSE[o] + ((l < a.L) ? 0.f : INFINITY);  // +inf -> P = 0 for labels past L
             pdel = a.DELTA[o];
+            pkey = gz_mix32(seedmix ^ ((rowbase + (uint32_t)l) * 0x9E3779B1u));
         }
     };
-    auto commit = [&]() {  // registers -> both LDS images of each tile
+    auto commit = [&](int buf) {  // registers -> the tile images of buffer `buf`
+        float* tq = tiles + buf * TSZ;
 #pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            const int idx = tid + NT * i, r = idx / (4 * ES), c = idx % (4 * ES);
-            if (r < BWD_BL) {
-                Qp[r * RSQ + (c & 3) * KSQ + (c >> 2)] = pq[i];
-                QT[c * RST + r] = pq[i];
-            }
-        }
+        for (int i = 0; i < QPT; ++i)
+            if (q_lds[i] >= 0) *reinterpret_cast<vecG*>(tq + q_lds[i]) = pq[i];
 #pragma unroll
-        for (int i = 0; i < OPT; ++i) {
-            const int idx = tid + NT * i, r = idx / (16 * NFT), c = idx % (16 * NFT);
-            if (r < BWD_BL) {
-                Op[r * RSO + (c & 3) * KSO + (c >> 2)] = po[i];
-                OT[c * RST + r] = po[i];
-            }
-        }
+        for (int i = 0; i < OPT; ++i)
+            if (o_lds[i] >= 0) *reinterpret_cast<vecG*>(tq + TQ + o_lds[i]) = po[i];
         if (tid < BWD_BL) {
-            lse_s[tid] = plse;
-            del_s[tid] = pdel;
+            float* ax = aux + buf * 48;
+            ax[tid] = plse;
+            ax[16 + tid] = pdel;
+            ax[32 + tid] = __uint_as_float(pkey);
         }
     };
 
@@ -535,72 +554,96 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     auto step_of = [&](int i) { int s = i + rot; return step_beg + (s >= nsteps ? s - nsteps : s); };
     if (nsteps > 0) {
         prefetch(step_of(0));
-        commit();
+        commit(0);
     }
     __syncthreads();
 
-    float* dSs = sm + P::oDS;
-    const float* Kw = Kp + (wave * 16) * RSQ;  // this wave's 16 keys
+    // lane constants of the two read patterns
+    const int xk = 4 * (lq ^ swz(lr));  // "along k": chunk (4g + lq) of row lr sits at float 16g + xk
+    int xrem[REM > 0 ? REM : 1];        // leftover S steps: column 16NG + 4j + lq of row lr
+#pragma unroll
+    for (int j = 0; j < REM; ++j) xrem[j] = 16 * NG + 4 * (j ^ swz(lr)) + lq;
+    // "along rows": row 4lq + r has swz = (2lq + (r >> 1)) & 3; h = r >> 1
+    int x4[2], x2[2], x1[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int sw = (2 * lq + h) & 3;
+        x4[h] = 4 * (lr ^ sw);                         // four-tile groups: columns 64jg + 4lr ..
+        x2[h] = 4 * ((lr >> 1) ^ sw) + 2 * (lr & 1);   // pair: columns 2lr, 2lr + 1
+        x1[h] = 4 * ((lr >> 2) ^ sw) + (lr & 3);       // single tile: column lr
+    }
+    const float* Kw = Kp + (wave * 16 + lr) * RSQ;  // this lane's key row
     // dQ[l, e] = sum_tok dS[l, tok] K[tok, e] sums over the tokens of ALL waves.  The waves exchange dS through one
     // LDS tile and wave w owns output columns e in [16w, 16w+16) over the whole 16*NW-token K range: no cross-wave
     // reduction (LDS float atomics ran at < 1 lane/clk/CU and cost 3/4 of the kernel).  The product for step i runs
-    // inside step i+1 (double-buffered dS tile), so it needs no barrier of its own.
-    auto dq_tile = [&](int buf_prev) {
-        const float* dsp = dSs + buf_prev * BWD_BL * RSD;
+    // inside step i+1 and its flush inside step i+2 (double-buffered dS and dQ tiles): ONE barrier per step.
+    auto dq_tile = [&](int buf) {
+        const float* dsp = dSs + buf * BWD_BL * RSD;
+        float* dqo = dQs + buf * BWD_BL * DQW;
         for (int j = wave; j < NET; j += NW) {
             f32x4 q0 = f32x4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
-            const f32x4v* ap = reinterpret_cast<const f32x4v*>(dsp + lr * RSD + lq * KSD);  // dS[label lr][tok 4s+lq]
-            // K[tok = 4s + lq][e = 16j + lr] in the permuted image: column (lr & 3)*ESP + 4j + (lr >> 2)
-            const float* kq = Kp + lq * RSQ + (lr & 3) * KSQ + 4 * j + (lr >> 2);
+            const f32x4* ap = reinterpret_cast<const f32x4*>(dsp + lr * RSD + lq * KSD);  // dS[label lr][tok 4s+lq]
+            // K[tok = 4s + lq][e = 16j + lr]: row 4s + lq has swz = (2(s & 1) + (lq >> 1)) & 3
+            const float* kq0 = Kp + lq * RSQ + 16 * j + 4 * ((lr >> 2) ^ (lq >> 1)) + (lr & 3);
+            const float* kq1 = Kp + lq * RSQ + 16 * j + 4 * ((lr >> 2) ^ (2 + (lq >> 1))) + (lr & 3);
 #pragma unroll
             for (int g = 0; g < NW; ++g) {
-                const f32x4v av = ap[g];
+                const f32x4 av = ap[g];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float kv = kq[(4 * (4 * g + i)) * RSQ];
+                    const float kv = ((i & 1) ? kq1 : kq0)[(4 * (4 * g + i)) * RSQ];
                     if (i & 1) q1 = mfma16(av[i], kv, q1);
                     else q0 = mfma16(av[i], kv, q0);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dQs[(4 * lq + r) * DQW + 16 * j + lr] = q0[r] + q1[r];
+            for (int r = 0; r < 4; ++r) dqo[(4 * lq + r) * DQW + 16 * j + lr] = q0[r] + q1[r];
         }
     };
-    auto dq_flush = [&](int l0p) {  // row-contiguous float atomics; fixed trip count, unrolled (no vmcnt(0) drain)
+    auto dq_flush = [&](int buf, int l0p) {  // row-contiguous float atomics; fixed trip count, unrolled
+        const float* dqo = dQs + buf * BWD_BL * DQW;
 #pragma unroll
         for (int i = 0; i < DQF; ++i) {
             const int idx = tid + NT * i;
             const int r = idx / DQW, c = idx % DQW;
             if (idx < BWD_BL * DQW && c < a.E && l0p + r < a.L)
-                atomicAdd(a.dQ + (long long)(l0p + r) * a.E + c, dQs[idx]);
+                atomicAdd(a.dQ + (long long)(l0p + r) * a.E + c, dqo[idx]);
         }
     };
-    int l0_prev = 0;
+
+    int l0_p1 = 0, l0_p2 = 0;  // first labels of the previous two steps
     for (int it = 0; it < nsteps; ++it) {
-        const int step = step_of(it);
-        const int l0 = step * BWD_BL;
+        const int cur = it & 1;
+        const int l0 = step_of(it) * BWD_BL;
         const bool more = it + 1 < nsteps;
-        if (more && !(GZ_ABL & 8)) prefetch(step_of(it + 1));  // in flight during the MFMAs below
+        if (more && !(GZ_ABL & 8)) prefetch(step_of(it + 1));  // in flight during the whole step
+        if (it > 1 && !(GZ_ABL & 1)) dq_flush(cur, l0_p2);     // dQ tile of step it-2 (completed before the last barrier)
+        const float* tq = tiles + cur * TSZ;
+        const float* to = tq + TQ;
+        const float* ax = aux + cur * 48;
         // S tile (rows = labels l0 + 4lq + r, cols = tokens) and dP tile; two accumulators each (40-cycle latency)
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
         if (!(GZ_ABL & 32)) {
-            const f32x4v* qp = reinterpret_cast<const f32x4v*>(Qp + lr * RSQ + lq * KSQ);
-            const f32x4v* kp = reinterpret_cast<const f32x4v*>(Kw + lr * RSQ + lq * KSQ);
+            const float* qp = tq + lr * RSQ;
 #pragma unroll
-            for (int g = 0; g < ESP / 4; ++g) {
-                const f32x4v qa = qp[g], ka = kp[g];
+            for (int g = 0; g < NG; ++g) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(qp + 16 * g + xk);
+                const f32x4 ka = *reinterpret_cast<const f32x4*>(Kw + 16 * g + xk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (4 * g + i < ES) {
-                        if (i & 1) s1 = mfma16(qa[i], ka[i], s1);
-                        else s0 = mfma16(qa[i], ka[i], s0);
-                    }
+                    if (i & 1) s1 = mfma16(qa[i], ka[i], s1);
+                    else s0 = mfma16(qa[i], ka[i], s0);
                 }
             }
-            const f32x4v* op = reinterpret_cast<const f32x4v*>(Op + lr * RSO + lq * KSO);
 #pragma unroll
-            for (int g = 0; g < FS / 4; ++g) {
-                const f32x4v oa = op[g];
+            for (int j = 0; j < REM; ++j) {
+                if (j & 1) s1 = mfma16(qp[xrem[j]], Kw[xrem[j]], s1);
+                else s0 = mfma16(qp[xrem[j]], Kw[xrem[j]], s0);
+            }
+            const float* op = to + lr * RSO;
+#pragma unroll
+            for (int g = 0; g < NFT; ++g) {
+                const f32x4 oa = *reinterpret_cast<const f32x4*>(op + 16 * g + xk);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (i & 1) d1 = mfma16(oa[i], vT[4 * g + i], d1);
@@ -610,76 +653,85 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         }
         float pd[4], ds[4];
         {
-            const f32x4v lse4 = *reinterpret_cast<const f32x4v*>(lse_s + 4 * lq);
-            const f32x4v del4 = *reinterpret_cast<const f32x4v*>(del_s + 4 * lq);
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(ax + 4 * lq);
+            const f32x4 del4 = *reinterpret_cast<const f32x4*>(ax + 16 + 4 * lq);
+            const f32x4 key4 = *reinterpret_cast<const f32x4*>(ax + 32 + 4 * lq);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
                 float dsc = 1.f;
-                if (a.thresh && !(GZ_ABL & 4)) {
-                    const uint32_t key = gz_mix32(seedmix ^ ((rowbase + (uint32_t)(l0 + 4 * lq + r)) * 0x9E3779B1u));
-                    dsc = (gz_u32(key, (uint32_t)tok) >= a.thresh) ? a.scale : 0.f;
-                }
+                if (a.thresh && !(GZ_ABL & 4))
+                    dsc = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
                 pd[r] = p * dsc;
                 ds[r] = p * ((d0[r] + d1[r]) * dsc - del4[r]);
             }
         }
         // publish this wave's dS block (label 4lq + r, token 16*wave + lr) into the step's dS tile
         {
-            float* dw = dSs + (it & 1) * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * KSD + 4 * wave + (lr >> 2);
+            float* dw = dSs + cur * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * KSD + 4 * wave + (lr >> 2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) dw[r * RSD] = ds[r];
         }
-        // dV^T[f, tok] += sum_l dO[l, f] Pd[l, tok] ;  dK^T[e, tok] += sum_l Q[l, e] dS[l, tok]
-        // one b128 read = the four k-steps of one accumulator tile; two tiles in flight alternate (independent MFMAs)
+        // dV[tok, f] += sum_l Pd[l, tok] dO[l, f] ;  dK[tok, e] += sum_l dS[l, tok] Q[l, e].  k step r pairs labels
+        // {4q + r}: A = pd[r] / ds[r] straight from the S-tile registers, B = row 4lq + r of the dO / Q image.
         if (!(GZ_ABL & 2)) {
-            const float* op = OT + lr * RST + 4 * lq;
+            constexpr int FG4 = NFT / 4 * 4, EG4 = NET / 4 * 4;
+            constexpr bool F2 = (NFT - FG4) >= 2, F1 = ((NFT - FG4) & 1) != 0;
+            constexpr bool E2 = (NET - EG4) >= 2, E1 = ((NET - EG4) & 1) != 0;
 #pragma unroll
-            for (int j = 0; j < NFT; j += 2) {
-                const f32x4v a0 = *reinterpret_cast<const f32x4v*>(op + (16 * j) * RST);
-                f32x4v a1 = a0;
-                if (j + 1 < NFT) a1 = *reinterpret_cast<const f32x4v*>(op + (16 * (j + 1)) * RST);
+            for (int r = 0; r < 4; ++r) {
+                const float* orow = to + (4 * lq + r) * RSO;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    dVT[j] = mfma16(a0[s], pd[s], dVT[j]);
-                    if (j + 1 < NFT) dVT[j + 1] = mfma16(a1[s], pd[s], dVT[j + 1]);
+                for (int jg = 0; jg < NFT / 4; ++jg) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(orow + 64 * jg + x4[r >> 1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dV[4 * jg + e] = mfma16(pd[r], v4[e], dV[4 * jg + e]);
                 }
+                if (F2) {
+                    const f32x2 v2 = *reinterpret_cast<const f32x2*>(orow + 16 * FG4 + x2[r >> 1]);
+                    dV[FG4] = mfma16(pd[r], v2[0], dV[FG4]);
+                    dV[FG4 + 1] = mfma16(pd[r], v2[1], dV[FG4 + 1]);
+                }
+                if (F1) dV[NFT - 1] = mfma16(pd[r], orow[16 * (FG4 + (F2 ? 2 : 0)) + x1[r >> 1]], dV[NFT - 1]);
             }
-            const float* qp = QT + lr * RST + 4 * lq;
 #pragma unroll
-            for (int j = 0; j < NET; j += 2) {
-                const f32x4v a0 = *reinterpret_cast<const f32x4v*>(qp + (16 * j) * RST);
-                f32x4v a1 = a0;
-                if (j + 1 < NET) a1 = *reinterpret_cast<const f32x4v*>(qp + (16 * (j + 1)) * RST);
+            for (int r = 0; r < 4; ++r) {
+                const float* qrow = tq + (4 * lq + r) * RSQ;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    dKT[j] = mfma16(a0[s], ds[s], dKT[j]);
-                    if (j + 1 < NET) dKT[j + 1] = mfma16(a1[s], ds[s], dKT[j + 1]);
+                for (int jg = 0; jg < NET / 4; ++jg) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(qrow + 64 * jg + x4[r >> 1]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dK[4 * jg + e] = mfma16(ds[r], v4[e], dK[4 * jg + e]);
                 }
+                if (E2) {
+                    const f32x2 v2 = *reinterpret_cast<const f32x2*>(qrow + 16 * EG4 + x2[r >> 1]);
+                    dK[EG4] = mfma16(ds[r], v2[0], dK[EG4]);
+                    dK[EG4 + 1] = mfma16(ds[r], v2[1], dK[EG4 + 1]);
+                }
+                if (E1) dK[NET - 1] = mfma16(ds[r], qrow[16 * (EG4 + (E2 ? 2 : 0)) + x1[r >> 1]], dK[NET - 1]);
             }
         }
-        // dQ of the PREVIOUS step (its dS tile was completed before that step's first barrier)
-        if (it > 0 && !(GZ_ABL & 1)) dq_tile((it - 1) & 1);
-        __syncthreads();  // tiles fully consumed; previous step's dQ tile and this step's dS tile complete
-        if (it > 0 && !(GZ_ABL & 1)) dq_flush(l0_prev);
-        if (more && !(GZ_ABL & 8)) commit();
-        l0_prev = l0;
+        // dQ of the PREVIOUS step (its dS tile was completed before the last barrier)
+        if (it > 0 && !(GZ_ABL & 1)) dq_tile(cur ^ 1);
+        if (more && !(GZ_ABL & 8)) commit(cur ^ 1);  // next step's tiles: that buffer's readers passed the last barrier
+        l0_p2 = l0_p1;
+        l0_p1 = l0;
         __syncthreads();
     }
-    if (nsteps > 0 && !(GZ_ABL & 1)) {  // dQ of the last step
-        dq_tile((nsteps - 1) & 1);
+    if (nsteps > 0 && !(GZ_ABL & 1)) {  // drain: dQ of the last step, flushes of the last two
+        const int last = (nsteps - 1) & 1;
+        dq_tile(last);
+        if (nsteps > 1) dq_flush(last ^ 1, l0_p2);
         __syncthreads();
-        dq_flush(l0_prev);
+        dq_flush(last, l0_p1);
     }
     __syncthreads();
-    if (GZ_ABL & 2) {  // keep the accumulators' producers alive in ablation builds
-        dKT[0][0] += 0.f;
-    }
-    // epilogue: dK^T / dV^T tiles -> token-major rows through per-wave LDS staging, row-contiguous atomics
+    if (GZ_ABL & 2) dK[0][0] += 0.f;
+    // epilogue: dK / dV tiles -> token rows through per-wave LDS staging, row-contiguous atomics
     if (!(GZ_ABL & 16)) {
-        float* st = sm + wave * 16 * BWD_STW;
-        flush_tiles<NET>(dKT, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
-        flush_tiles<NFT>(dVT, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
+        float* st = sm + wave * 16 * P::STW;
+        flush_rows<NET, P::STW>(dK, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
+        flush_rows<NFT, P::STW>(dV, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
     }
 }
 
@@ -703,8 +755,10 @@ static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     using P = BwdLds<ES, NFT, NW>;
     static_assert(P::floats * 4 <= 160 * 1024, "backward LDS plan exceeds 160 KiB");
     const int nTT = cdiv(a.Tp, 16 * NW);
-    hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW>), dim3(a.B * nTT * a.nsplit), dim3(NW * 64),
-                       (size_t)P::floats * 4, st, a);
+    const dim3 grid(a.B * nTT * a.nsplit), block(NW * 64);
+    const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 && (((uintptr_t)a.Q | (uintptr_t)a.dO) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4>), grid, block, (size_t)P::floats * 4, st, a);
+    else hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1>), grid, block, (size_t)P::floats * 4, st, a);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
