@@ -508,25 +508,29 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         o_lds[i] = (r < BWD_BL) ? img_off(r, c, RSO) : -1;
     }
     vecG pq[QPT], po[OPT];
-    float plse = 0.f, pdel = 0.f;
+    float plse = 0.f, pdel = 0.f, plinf = 0.f;
     uint32_t pkey = 0;
     // Straight-line loads from CLAMPED addresses, no validity selects (a `cond ? load : 0` makes hipcc branch around
     // each load and wait vmcnt(0) inside the branch).  Rows past L are neutralised through lse = +inf (P = 0, so
     // dS = Pd = 0 whatever finite Q / dO row was read); columns past E / F meet zero key / value pads, or produce
     // accumulator columns that are never stored.
+    const float* dOb = a.dO + (long long)b * a.L * a.F;   // in-note offsets fit 32 bits (L*F, L*E < 2^31: checked on the host)
+    const float* lseb = a.LSE + (long long)b * a.L;
+    const float* delb = a.DELTA + (long long)b * a.L;
     auto prefetch = [&](int step) {
         const int l0 = step * BWD_BL;
 #pragma unroll
         for (int i = 0; i < QPT; ++i)
-            pq[i] = *reinterpret_cast<const vecG*>(a.Q + (long long)min(l0 + q_row[i], a.L - 1) * a.E + q_col[i]);
+            pq[i] = *reinterpret_cast<const vecG*>(a.Q + (unsigned)(min(l0 + q_row[i], a.L - 1) * a.E + q_col[i]));
 #pragma unroll
         for (int i = 0; i < OPT; ++i)
-            po[i] = *reinterpret_cast<const vecG*>(a.dO + ((long long)b * a.L + min(l0 + o_row[i], a.L - 1)) * a.F + o_col[i]);
+            po[i] = *reinterpret_cast<const vecG*>(dOb + (unsigned)(min(l0 + o_row[i], a.L - 1) * a.F + o_col[i]));
         {
             const int l = l0 + (tid & (BWD_BL - 1));
-            const long long o = (long long)b * a.L + min(l, a.L - 1);
-            plse = a.LSE[o] + ((l < a.L) ? 0.f : INFINITY);  // +inf -> P = 0 for labels past L
-            pdel = a.DELTA[o];
+            const unsigned o = (unsigned)min(l, a.L - 1);
+            plse = lseb[o];
+            pdel = delb[o];
+            plinf = (l < a.L) ? 0.f : INFINITY;  // added at commit time (nothing may wait on a load here)
             pkey = gz_mix32(seedmix ^ ((rowbase + (uint32_t)l) * 0x9E3779B1u));
         }
     };
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
             if (o_lds[i] >= 0) *reinterpret_cast<vecG*>(tq + TQ + o_lds[i]) = po[i];
         if (tid < BWD_BL) {
             float* ax = aux + buf * 48;
-            ax[tid] = plse;
+            ax[tid] = plse + plinf;  // +inf -> P = 0 for labels past L
             ax[16 + tid] = pdel;
             ax[32 + tid] = __uint_as_float(pkey);
         }
@@ -803,6 +807,7 @@ extern "C" int gzsl_label_attn_bwd(const float* dO, const float* PX, const float
                                    float drop_scale, void* stream) {
     if (B <= 0 || L <= 0) return 0;
     if (Tp <= 0 || E <= 0 || F <= 0 || nsplit <= 0) return GZSL_EINVAL;
+    if ((long long)L * F >= (1ll << 31) || (long long)L * E >= (1ll << 31)) return GZSL_EINVAL;  // 32-bit in-note offsets
     AttnBwdArgs a{dO, PX, X, Q, LSE, DELTA, dPX, dX, dQ, B, Tp, E, F, L, l_offset, L_total, nsplit, seed, drop_thresh,
                   drop_scale};
     hipStream_t st = (hipStream_t)stream;
