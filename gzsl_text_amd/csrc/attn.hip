@@ -628,30 +628,61 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         // S tile (rows = labels l0 + 4lq + r, cols = tokens) and dP tile; two accumulators each (40-cycle latency)
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
         if (!(GZ_ABL & 32)) {
+            // One flat sequence of items (NG key/query groups, then NFT dO groups), each read one item ahead of its
+            // MFMAs and pinned there: the compiler otherwise issues every ds_read right before its use, and each group
+            // of four MFMAs then waits out a full LDS latency.
             const float* qp = tq + lr * RSQ;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const f32x4 qa = *reinterpret_cast<const f32x4*>(qp + 16 * g + xk);
-                const f32x4 ka = *reinterpret_cast<const f32x4*>(Kw + 16 * g + xk);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i & 1) s1 = mfma16(qa[i], ka[i], s1);
-                    else s0 = mfma16(qa[i], ka[i], s0);
+            const float* op = to + lr * RSO;
+            constexpr int NI = NG + NFT;
+            f32x4 fa[2], fb[2];
+            auto ld = [&](int it, int slot) {
+                if (it < NG) {
+                    fa[slot] = *reinterpret_cast<const f32x4*>(qp + 16 * it + xk);
+                    fb[slot] = *reinterpret_cast<const f32x4*>(Kw + 16 * it + xk);
+                } else {
+                    fa[slot] = *reinterpret_cast<const f32x4*>(op + 16 * (it - NG) + xk);
                 }
-            }
+            };
+            float rq[REM > 0 ? REM : 1], rk[REM > 0 ? REM : 1];
 #pragma unroll
             for (int j = 0; j < REM; ++j) {
-                if (j & 1) s1 = mfma16(qp[xrem[j]], Kw[xrem[j]], s1);
-                else s0 = mfma16(qp[xrem[j]], Kw[xrem[j]], s0);
+                rq[j] = qp[xrem[j]];
+                rk[j] = Kw[xrem[j]];
             }
-            const float* op = to + lr * RSO;
+            ld(0, 0);
 #pragma unroll
-            for (int g = 0; g < NFT; ++g) {
-                const f32x4 oa = *reinterpret_cast<const f32x4*>(op + 16 * g + xk);
+            for (int it = 0; it < NI; ++it) {
+                if (it + 1 < NI) ld(it + 1, (it + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 av = fa[it & 1];
+                if (it < NG) {
+                    const f32x4 bv = fb[it & 1];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (i & 1) d1 = mfma16(oa[i], vT[4 * g + i], d1);
-                    else d0 = mfma16(oa[i], vT[4 * g + i], d0);
+                    for (int i = 0; i < 4; ++i) {
+                        if (i & 1) s1 = mfma16(av[i], bv[i], s1);
+                        else s0 = mfma16(av[i], bv[i], s0);
+                    }
+                    if (it == NG - 1) {
+#pragma unroll
+                        for (int j = 0; j < REM; ++j) {
+                            if (j & 1) s1 = mfma16(rq[j], rk[j], s1);
+                            else s0 = mfma16(rq[j], rk[j], s0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i & 1) d1 = mfma16(av[i], vT[4 * (it - NG) + i], d1);
+                        else d0 = mfma16(av[i], vT[4 * (it - NG) + i], d0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (NG == 0) {
+#pragma unroll
+                for (int j = 0; j < REM; ++j) {
+                    if (j & 1) s1 = mfma16(rq[j], rk[j], s1);
+                    else s0 = mfma16(rq[j], rk[j], s0);
                 }
             }
         }
@@ -682,37 +713,46 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
             constexpr int FG4 = NFT / 4 * 4, EG4 = NET / 4 * 4;
             constexpr bool F2 = (NFT - FG4) >= 2, F1 = ((NFT - FG4) & 1) != 0;
             constexpr bool E2 = (NET - EG4) >= 2, E1 = ((NET - EG4) & 1) != 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            // B fragments of k step r: one float per accumulator tile, read one k step ahead of its MFMAs
+            float bo[2][NFT], bq[2][NET];
+            auto ldrow = [&](int r, int slot) {
                 const float* orow = to + (4 * lq + r) * RSO;
+                const float* qrow = tq + (4 * lq + r) * RSQ;
 #pragma unroll
                 for (int jg = 0; jg < NFT / 4; ++jg) {
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(orow + 64 * jg + x4[r >> 1]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dV[4 * jg + e] = mfma16(pd[r], v4[e], dV[4 * jg + e]);
+                    for (int e = 0; e < 4; ++e) bo[slot][4 * jg + e] = v4[e];
                 }
                 if (F2) {
                     const f32x2 v2 = *reinterpret_cast<const f32x2*>(orow + 16 * FG4 + x2[r >> 1]);
-                    dV[FG4] = mfma16(pd[r], v2[0], dV[FG4]);
-                    dV[FG4 + 1] = mfma16(pd[r], v2[1], dV[FG4 + 1]);
+                    bo[slot][FG4] = v2[0];
+                    bo[slot][FG4 + 1] = v2[1];
                 }
-                if (F1) dV[NFT - 1] = mfma16(pd[r], orow[16 * (FG4 + (F2 ? 2 : 0)) + x1[r >> 1]], dV[NFT - 1]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* qrow = tq + (4 * lq + r) * RSQ;
+                if (F1) bo[slot][NFT - 1] = orow[16 * (FG4 + (F2 ? 2 : 0)) + x1[r >> 1]];
 #pragma unroll
                 for (int jg = 0; jg < NET / 4; ++jg) {
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(qrow + 64 * jg + x4[r >> 1]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dK[4 * jg + e] = mfma16(ds[r], v4[e], dK[4 * jg + e]);
+                    for (int e = 0; e < 4; ++e) bq[slot][4 * jg + e] = v4[e];
                 }
                 if (E2) {
                     const f32x2 v2 = *reinterpret_cast<const f32x2*>(qrow + 16 * EG4 + x2[r >> 1]);
-                    dK[EG4] = mfma16(ds[r], v2[0], dK[EG4]);
-                    dK[EG4 + 1] = mfma16(ds[r], v2[1], dK[EG4 + 1]);
+                    bq[slot][EG4] = v2[0];
+                    bq[slot][EG4 + 1] = v2[1];
                 }
-                if (E1) dK[NET - 1] = mfma16(ds[r], qrow[16 * (EG4 + (E2 ? 2 : 0)) + x1[r >> 1]], dK[NET - 1]);
+                if (E1) bq[slot][NET - 1] = qrow[16 * (EG4 + (E2 ? 2 : 0)) + x1[r >> 1]];
+            };
+            ldrow(0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r + 1 < 4) ldrow(r + 1, (r + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NFT; ++j) dV[j] = mfma16(pd[r], bo[r & 1][j], dV[j]);
+#pragma unroll
+                for (int j = 0; j < NET; ++j) dK[j] = mfma16(ds[r], bq[r & 1][j], dK[j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // dQ of the PREVIOUS step (its dS tile was completed before the last barrier)
