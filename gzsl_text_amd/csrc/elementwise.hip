@@ -53,6 +53,84 @@ __global__ void emb_scatter_kernel(float* __restrict__ dW, const int64_t* __rest
     }
 }
 
+// ---- scatter-add grouped by id inside 128-row chunks ------------------------------------------------------------------
+// Word ids follow a Zipf law: thousands of rows of a note batch add into the same few embedding rows, and same-address
+// float atomics serialise at the memory side (MI355X_MICROARCH.md: "every workgroup into ONE row: 14x slower").  Each
+// workgroup sorts the ids of its 128 consecutive rows in LDS (bitonic), stages the rows' gradients in sorted order and
+// sums runs of equal ids down the columns: one atomic per (run, column) instead of one per (row, column).
+#define ES_CHUNK 128
+__global__ __launch_bounds__(256) void emb_scatter_grouped_kernel(
+    float* __restrict__ dW, const int64_t* __restrict__ ids, const float* __restrict__ mask,
+    const float* __restrict__ dOut, long long rows, int E, int64_t pad_idx, long long row_offset, uint32_t seed,
+    uint32_t thresh, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char es_smem[];
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(es_smem);  // [128] (id << 8 | row in chunk)
+    float* tile = reinterpret_cast<float*>(key + ES_CHUNK);                      // [128][E], rows in sorted order
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * ES_CHUNK;
+    if (tid < ES_CHUNK) {
+        const long long r = r0 + tid;
+        unsigned long long k = ~0ull;  // rows past the end and padding ids sort last and are skipped
+        if (r < rows) {
+            const int64_t id = ids[r];
+            if (id != pad_idx && id >= 0) k = ((unsigned long long)id << 8) | (unsigned)tid;
+        }
+        key[tid] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= ES_CHUNK; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < ES_CHUNK) {
+                const int j = tid ^ stride;
+                if (j > tid) {
+                    const unsigned long long a = key[tid], b = key[j];
+                    const bool up = (tid & size) == 0;
+                    if ((a > b) == up) {
+                        key[tid] = b;
+                        key[j] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int idx = tid; idx < ES_CHUNK * E; idx += 256) {
+        const int j = idx / E, e = idx - j * E;
+        const unsigned long long k = key[j];
+        float v = 0.f;
+        if (k != ~0ull) {
+            const long long r = r0 + (long long)(k & 255);
+            v = dOut[r * E + e];
+            if (mask) v *= mask[r];
+            if (thresh) {
+                const uint32_t u = gz_u32(gz_row_key(seed, GZSL_STREAM_EMB, (uint32_t)(r + row_offset)), (uint32_t)e);
+                v = (u >= thresh) ? v * scale : 0.f;
+            }
+        }
+        tile[idx] = v;
+    }
+    __syncthreads();
+    // thread (half, e): sums runs of equal ids over 64 sorted rows of column e
+    const int halves = E <= 128 ? 2 : 1, per = ES_CHUNK / halves;
+    const int half = E <= 128 ? tid >> 7 : 0;
+    for (int e = E <= 128 ? (tid & 127) : tid; e < E; e += E <= 128 ? 128 : 256) {
+        float acc = 0.f;
+        unsigned long long cur = key[half * per] >> 8;
+        for (int j = half * per; j < (half + 1) * per; ++j) {
+            const unsigned long long k = key[j];
+            if (k == ~0ull) break;
+            const unsigned long long id = k >> 8;
+            if (id != cur) {
+                if (acc != 0.f) atomicAdd(dW + (long long)cur * E + e, acc);
+                acc = 0.f;
+                cur = id;
+            }
+            acc += tile[j * E + e];
+        }
+        if (acc != 0.f) atomicAdd(dW + (long long)cur * E + e, acc);
+    }
+}
+
 __global__ void label_avg_fwd_kernel(const float* __restrict__ W, const int64_t* __restrict__ idx,
                                      const float* __restrict__ mask, float* __restrict__ out, int N, int Td, int E) {
     const long long n = (long long)N * E;
@@ -300,6 +378,18 @@ extern "C" int gzsl_emb_scatter_add(float* dW, const int64_t* ids, const float* 
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(emb_scatter_kernel, dim3(ew_blocks(rows * E)), dim3(EW_THREADS), 0, ST, dW, ids, mask, dOut, rows,
                        E, pad_idx, row_offset, seed, drop_thresh, drop_scale);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_emb_scatter_add_grouped(float* dW, const int64_t* ids, const float* mask, const float* dOut,
+                                            long long rows, int E, int64_t pad_idx, long long row_offset,
+                                            uint32_t seed, uint32_t drop_thresh, float drop_scale, void* stream) {
+    if (rows <= 0) return 0;
+    const size_t smem = sizeof(unsigned long long) * ES_CHUNK + sizeof(float) * ES_CHUNK * (size_t)E;
+    if (E <= 0 || smem > 150 * 1024) return GZSL_EINVAL;  // E <= 297 (the reference uses 100 or 200)
+    hipLaunchKernelGGL(emb_scatter_grouped_kernel, dim3((unsigned)((rows + ES_CHUNK - 1) / ES_CHUNK)), dim3(256), smem, ST,
+                       dW, ids, mask, dOut, rows, E, pad_idx, row_offset, seed, drop_thresh, drop_scale);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

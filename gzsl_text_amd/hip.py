@@ -39,6 +39,7 @@ _PROTOS = {
     'gzsl_label_attn_bwd': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p],
     'gzsl_emb_gather_fwd': [c_void_p] * 4 + [c_ll, c_int, c_ll, c_u32, c_u32, c_float, c_void_p],
     'gzsl_emb_scatter_add': [c_void_p] * 4 + [c_ll, c_int, c_ll, c_ll, c_u32, c_u32, c_float, c_void_p],
+    'gzsl_emb_scatter_add_grouped': [c_void_p] * 4 + [c_ll, c_int, c_ll, c_ll, c_u32, c_u32, c_float, c_void_p],
     'gzsl_label_avg_fwd': [c_void_p] * 4 + [c_int] * 3 + [c_void_p],
     'gzsl_label_avg_bwd': [c_void_p] * 4 + [c_int] * 3 + [c_ll, c_void_p],
     'gzsl_spmm_csr': [c_void_p] * 7 + [c_int] * 3 + [c_void_p],

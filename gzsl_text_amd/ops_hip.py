@@ -116,8 +116,10 @@ class HipOps:
 
     def emb_scatter_add_(self, dW, ids, mask, dOut, seed, p, pad_idx=0, row_offset=0):
         th, sc = drop_params(p)
-        call('gzsl_emb_scatter_add', ptr(dW), ptr(ids), ptr(mask), ptr(dOut), ids.numel(), dW.shape[1], pad_idx,
-             row_offset, seed & 0xFFFFFFFF, th, sc)
+        rows, E = ids.numel(), dW.shape[1]
+        # many rows per id (word ids are Zipf-distributed): sum runs of equal ids inside 128-row chunks first
+        name = 'gzsl_emb_scatter_add_grouped' if (rows >= 1024 and E <= 297) else 'gzsl_emb_scatter_add'
+        call(name, ptr(dW), ptr(ids), ptr(mask), ptr(dOut), rows, E, pad_idx, row_offset, seed & 0xFFFFFFFF, th, sc)
         return dW
 
     def conv_relu(self, e, Wc, bc):

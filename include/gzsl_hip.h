@@ -78,6 +78,11 @@ int gzsl_emb_gather_fwd(const float* W, const int64_t* ids, const float* mask, f
 int gzsl_emb_scatter_add(float* dW, const int64_t* ids, const float* mask, const float* dOut, long long rows, int E,
                          int64_t pad_idx, long long row_offset, uint32_t seed, uint32_t drop_thresh, float drop_scale,
                          void* stream);
+/* Same result (up to fp32 summation order), for id streams with heavy repeats (word ids are Zipf-distributed): each
+ * workgroup sorts the ids of 128 consecutive rows in LDS and sums runs of equal ids before the atomics.  E <= 297. */
+int gzsl_emb_scatter_add_grouped(float* dW, const int64_t* ids, const float* mask, const float* dOut, long long rows,
+                                 int E, int64_t pad_idx, long long row_offset, uint32_t seed, uint32_t drop_thresh,
+                                 float drop_scale, void* stream);
 /* icd_modules.py:110-113 average_label_embedding: out[n,:] = sum_j mask[n,j] W[idx[n,j],:] / sum_j mask[n,j] */
 int gzsl_label_avg_fwd(const float* W, const int64_t* idx, const float* mask, float* out, int N, int Td, int E,
                        void* stream);

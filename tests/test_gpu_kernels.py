@@ -96,6 +96,22 @@ def test_embedding_gather_scatter(ops, ref, p):
     assert float(dW[0].abs().sum()) == 0.0, 'padding row must get no gradient'
 
 
+def test_embedding_scatter_grouped_by_id(ops, ref):
+    """>= 4096 rows take the grouped path (histogram / scan / fill / segmented sums); heavy repeats as in word ids."""
+    rs = np.random.RandomState(11)
+    V, E, B, T = 700, 100, 4, 1500
+    ids = np.minimum((rs.zipf(1.3, size=(B, T)) - 1), V - 1).astype(np.int64)  # id 0 (padding) is the most frequent
+    ids[0, :50] = V - 1
+    ids = torch.from_numpy(ids)
+    mask = torch.from_numpy((rs.random_sample((B, T)) < 0.9).astype(np.float32))
+    dOut = rnd(rs, B, T, E)
+    for p in (0.0, 0.5):
+        dW = ops.emb_scatter_add_(torch.zeros(V, E, device=DEV), g(ids), g(mask), g(dOut), 5, p, row_offset=3)
+        dWr = ref.emb_scatter_add_(torch.zeros(V, E), ids, mask, dOut, 5, p, row_offset=3)
+        close(dW, dWr, 1e-5, 2e-4, f'grouped emb scatter p={p}')  # sums of up to ~2000 terms in a different order
+        assert float(dW[0].abs().sum()) == 0.0, 'padding row must get no gradient'
+
+
 def test_label_side_kernels(ops, ref):
     rs = np.random.RandomState(4)
     V, E, N, Td, H = 60, 100, 45, 7, 100
