@@ -68,7 +68,7 @@ __device__ __forceinline__ int fwd_f(int j, int i) {
 }
 
 // G = floats per staging load (4 when E and F are multiples of 4: 16-byte loads of the contiguous 32-row tile).
-template <int ES, int NFT, int G>
+template <int ES, int NFT, int G, bool DROP>
 __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnFwdArgs a) {
     using P = FwdLds<ES, NFT>;
     constexpr int EP = P::EP, FP = P::FP, NG = P::NG, REM = P::REM, G4 = P::G4;
@@ -174,19 +174,29 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnF
             // S^T sub-tile: rows = tokens t0+16u+4lq+r, cols = labels
             f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
             const float* kp = Ks + (16 * u + lr) * EP;
+            // key groups are read one group ahead of their MFMAs and pinned there (otherwise every group of four
+            // MFMAs waits out the LDS latency of its own read)
+            float kr[REM > 0 ? REM : 1];
+#pragma unroll
+            for (int j = 0; j < REM; ++j) kr[j] = kp[16 * NG + 4 * j + lq];
+            f32x4 kf[2];
+            if (NG > 0) kf[0] = *reinterpret_cast<const f32x4*>(kp + 4 * lq);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + 16 * g + 4 * lq);
+                if (g + 1 < NG) kf[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(kp + 16 * (g + 1) + 4 * lq);
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 k4 = kf[g & 1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j & 1) s1 = mfma16(k4[j], qreg[4 * g + j], s1);
                     else s0 = mfma16(k4[j], qreg[4 * g + j], s0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int j = 0; j < REM; ++j) {
-                if (j & 1) s1 = mfma16(kp[16 * NG + 4 * j + lq], qreg[4 * NG + j], s1);
-                else s0 = mfma16(kp[16 * NG + 4 * j + lq], qreg[4 * NG + j], s0);
+                if (j & 1) s1 = mfma16(kr[j], qreg[4 * NG + j], s1);
+                else s0 = mfma16(kr[j], qreg[4 * NG + j], s0);
             }
             float sv[4];
             float mt = -INFINITY;
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnF
             for (int r = 0; r < 4; ++r) {
                 p[r] = __expf(sv[r] - m);
                 lsum += p[r];
-                if (a.thresh) {
+                if (DROP) {  // compile-time: a runtime test here splits the loop body into many basic blocks
                     const uint32_t uu = gz_u32(rowkey, (uint32_t)(tbase + r));
                     p[r] = (uu >= a.thresh) ? p[r] * a.scale : 0.f;
                 }
@@ -220,21 +230,30 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnF
             // O^T[f, label] += sum_t V[t, f] * P[t, label]; k step sp pairs tokens {4q + sp}.  sp outermost:
             // consecutive MFMAs hit different accumulators (the 16x16x4 form has a 40-cycle dependent latency)
             const float* vp = Vs + (16 * u + 4 * lq) * FP;
-#pragma unroll
-            for (int sp = 0; sp < 4; ++sp) {
+            float vf[2][NFT];  // A fragments of k step sp: one float per accumulator tile, read one k step ahead
+            auto ldv = [&](int sp, int slot) {
                 const float* vrow = vp + sp * FP;
 #pragma unroll
                 for (int gi = 0; gi < NFT / 4; ++gi) {
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(vrow + 64 * gi + 4 * lr);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[4 * gi + e] = mfma16(v4[e], p[sp], acc[4 * gi + e]);
+                    for (int e = 0; e < 4; ++e) vf[slot][4 * gi + e] = v4[e];
                 }
                 if (HAS2) {
                     const f32x2 v2 = *reinterpret_cast<const f32x2*>(vrow + 16 * G4 + 2 * lr);
-                    acc[G4] = mfma16(v2[0], p[sp], acc[G4]);
-                    acc[G4 + 1] = mfma16(v2[1], p[sp], acc[G4 + 1]);
+                    vf[slot][G4] = v2[0];
+                    vf[slot][G4 + 1] = v2[1];
                 }
-                if (HAS1) acc[NFT - 1] = mfma16(vrow[16 * (G4 + (HAS2 ? 2 : 0)) + lr], p[sp], acc[NFT - 1]);
+                if (HAS1) vf[slot][NFT - 1] = vrow[16 * (G4 + (HAS2 ? 2 : 0)) + lr];
+            };
+            ldv(0, 0);
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                if (sp + 1 < 4) ldv(sp + 1, (sp + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NFT; ++j) acc[j] = mfma16(vf[sp & 1][j], p[sp], acc[j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -784,10 +803,11 @@ static int launch_fwd(const AttnFwdArgs& a, hipStream_t st) {
     size_t smem = (size_t)FwdLds<ES, NFT>::floats * 4;
     const int nLT = cdiv(a.L, 16 * FWD_WAVES);
     const dim3 grid(a.B * nLT), block(FWD_WAVES * 64);
-    if ((a.E & 3) == 0 && (a.F & 3) == 0)
-        hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 4>), grid, block, smem, st, a);
-    else
-        hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 1>), grid, block, smem, st, a);
+    const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 && (((uintptr_t)a.PX | (uintptr_t)a.X) & 15) == 0;
+    if (vec && a.thresh) hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 4, true>), grid, block, smem, st, a);
+    else if (vec) hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 4, false>), grid, block, smem, st, a);
+    else if (a.thresh) hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 1, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 1, false>), grid, block, smem, st, a);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

@@ -331,19 +331,79 @@ __global__ void act_bwd_kernel(float* __restrict__ d, const float* __restrict__ 
 }
 
 // out[n] += sum_m x[m*ld + n]; block = 64 columns x 4 row-lanes, each block sweeps a row chunk
-__global__ void colsum_kernel(const float* __restrict__ x, float* out, long long M, int N, int ld, int rows_per_block) {
-    __shared__ float part[4][64];
+// V = columns per lane (4 with 16-byte loads when N, ld and the base allow it).  64 column lanes x 4 row lanes per block;
+// eight independent row streams per thread keep the loads in flight.
+template <int V>
+__global__ void colsum_kernel(const float* __restrict__ x, float* out, float* partial, long long M, int N, int ld,
+                              int rows_per_block) {
+    typedef float vecV __attribute__((ext_vector_type(V)));
+    __shared__ float part[4][64 * V];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cx;
+    const int col = (blockIdx.x * 64 + cx) * V;
     const long long r0 = (long long)blockIdx.y * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
+    float s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.f;
+    if (col < N) {
+        long long r = r0 + ry;
+        for (; r + 28 < r1; r += 32) {
+            vecV t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const vecV*>(x + (r + 4 * u) * ld + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int v = 0; v < V; ++v) s[v] += t[u][v];
+        }
+        for (; r < r1; r += 4) {
+            const vecV t = *reinterpret_cast<const vecV*>(x + r * ld + col);
+#pragma unroll
+            for (int v = 0; v < V; ++v) s[v] += t[v];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) part[ry][cx * V + v] = s[v];
+    __syncthreads();
+    if (ry == 0 && col < N) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = cx * V + v;
+            const float t = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+            // same-address float atomics cost ~100 ns each (serialised at the memory side): with a workspace the
+            // row blocks write partial sums and colsum_finish_kernel adds them up in a fixed order
+            if (partial) partial[(long long)blockIdx.y * N + col + v] = t;
+            else atomicAdd(out + col + v, t);
+        }
+    }
+}
+
+// 16 columns x 16 row lanes per block; fixed summation order
+__global__ void colsum_finish_kernel(const float* __restrict__ partial, float* out, int nblk, int N) {
+    __shared__ float part[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cx;
     float s = 0.f;
-    if (col < N)
-        for (long long r = r0 + ry; r < r1; r += 4) s += x[r * ld + col];
+    if (col < N) {
+        int b = ry;
+        for (; b + 48 < nblk; b += 64) {
+            float t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = partial[(long long)(b + 16 * u) * N + col];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += t[u];
+        }
+        for (; b < nblk; b += 16) s += partial[(long long)b * N + col];
+    }
     part[ry][cx] = s;
     __syncthreads();
-    if (ry == 0 && col < N) atomicAdd(out + col, part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+    if (ry == 0 && col < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += part[u][cx];
+        out[col] += t;
+    }
 }
 
 __global__ void conv_pack_kernel(const float* __restrict__ W, float* __restrict__ Wp, float* __restrict__ Wflip, int F,
@@ -501,18 +561,37 @@ extern "C" int gzsl_act_bwd(float* d, const float* y, long long n, int act, void
     return 0;
 }
 
-extern "C" int gzsl_colsum(const float* x, float* out, long long M, int N, int ld, void* stream) {
+static int colsum_launch(const float* x, float* out, long long M, int N, int ld, float* work, long long work_floats,
+                         hipStream_t st) {
     if (M <= 0 || N <= 0) return 0;
-    int rows_per_block = 256;
+    int rows_per_block = 128;
     long long gy = (M + rows_per_block - 1) / rows_per_block;
-    if (gy > 4096) {
-        rows_per_block = (int)((M + 4095) / 4096);
+    long long cap = 4096;
+    if (work && work_floats / N < cap) cap = work_floats / N;
+    if (cap < 1) work = nullptr, cap = 4096;
+    if (gy > cap) {
+        rows_per_block = (int)((M + cap - 1) / cap);
         gy = (M + rows_per_block - 1) / rows_per_block;
     }
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), (unsigned)gy), dim3(256), 0, ST, x, out, M, N, ld,
-                       rows_per_block);
+    if (gy <= 8) work = nullptr;  // a handful of atomics per column is cheaper than a second launch
+    if ((N & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(colsum_kernel<4>, dim3(cdiv(N, 256), (unsigned)gy), dim3(256), 0, st, x, out, work, M, N, ld,
+                           rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel<1>, dim3(cdiv(N, 64), (unsigned)gy), dim3(256), 0, st, x, out, work, M, N, ld,
+                           rows_per_block);
+    if (work) hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(N, 16)), dim3(256), 0, st, work, out, (int)gy, N);
     GZSL_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int gzsl_colsum(const float* x, float* out, long long M, int N, int ld, void* stream) {
+    return colsum_launch(x, out, M, N, ld, nullptr, 0, ST);
+}
+
+extern "C" int gzsl_colsum_ws(const float* x, float* out, long long M, int N, int ld, float* work, long long work_floats,
+                              void* stream) {
+    return colsum_launch(x, out, M, N, ld, work, work_floats, ST);
 }
 
 extern "C" int gzsl_conv_weight_pack(const float* W, float* Wp, float* Wflip, int F, int E, int k, void* stream) {

@@ -349,8 +349,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, long long s
     long long total = (long long)M * N;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
+        // fixed summation order (bitwise reproducible); eight loads in flight
         float s = 0.f;
-        for (int zz = 0; zz < nsplit; ++zz) s += slab[zz * stride + i];
+        int zz = 0;
+        for (; zz + 8 <= nsplit; zz += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = slab[(zz + u) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; zz < nsplit; ++zz) s += slab[zz * stride + i];
         int m = (int)(i / N), n = (int)(i % N);
         if (bias) s += bias[n];
         long long o;

@@ -98,7 +98,11 @@ class HipOps:
         assert x2d.stride(1) == 1
         if out is None:
             out = torch.zeros(N, dtype=torch.float32, device=x2d.device)
-        call('gzsl_colsum', x2d.data_ptr(), ptr(out), M, N, x2d.stride(0))
+        if M >= 4096:  # partial sums through a workspace instead of thousands of same-address atomics
+            work = torch.empty(min(512, (M + 127) // 128) * N, dtype=torch.float32, device=x2d.device)
+            call('gzsl_colsum_ws', x2d.data_ptr(), ptr(out), M, N, x2d.stride(0), ptr(work), work.numel())
+        else:
+            call('gzsl_colsum', x2d.data_ptr(), ptr(out), M, N, x2d.stride(0))
         return out
 
     def act_bwd_(self, d, y, act):

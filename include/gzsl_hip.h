@@ -117,7 +117,11 @@ int gzsl_adamw_nobias_step(float* p, const float* g, float* m, float* v, long lo
 
 /* ---- small elementwise / reductions used by the backward passes ------------------------------------------------ */
 int gzsl_act_bwd(float* d, const float* y, long long n, int act, void* stream); /* d *= act'(y), y = activated output */
-int gzsl_colsum(const float* x, float* out, long long M, int N, int ld, void* stream); /* out[n] += sum_m x[m*ld+n] */
+int gzsl_colsum(const float* x, float* out, long long M, int N, int ld, void* stream);
+/* Same, with a device workspace of work_floats floats (contents undefined): row blocks write partial sums there and a
+ * second launch adds them to out in a fixed order, instead of up to 4096 same-address atomics per column. */
+int gzsl_colsum_ws(const float* x, float* out, long long M, int N, int ld, float* work, long long work_floats,
+                   void* stream); /* out[n] += sum_m x[m*ld+n] */
 /* conv_modules.0.weight [F,E,k] -> Wp[f][j*E+e] (forward GEMM operand) and Wflip[e][j'*F+f] = W[f][e][k-1-j'] (data grad) */
 int gzsl_conv_weight_pack(const float* W, float* Wp, float* Wflip, int F, int E, int k, void* stream);
 

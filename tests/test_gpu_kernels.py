@@ -112,6 +112,16 @@ def test_embedding_scatter_grouped_by_id(ops, ref):
         assert float(dW[0].abs().sum()) == 0.0, 'padding row must get no gradient'
 
 
+@pytest.mark.parametrize('M,N,ld', [(20000, 200, 200), (5000, 37, 64), (300, 100, 100), (9000, 100, 300)])
+def test_colsum_workspace_and_atomic_paths(ops, M, N, ld):
+    rs = np.random.RandomState(M + N)
+    x = rnd(rs, M, ld)
+    xd = g(x)[:, :N]
+    out0 = rnd(rs, N)
+    out = ops.colsum(xd, out=g(out0).clone())  # accumulates into out
+    close(out, out0 + x[:, :N].double().sum(0).float(), 1e-5, 2e-5 * np.sqrt(M), 'colsum')
+
+
 def test_label_side_kernels(ops, ref):
     rs = np.random.RandomState(4)
     V, E, N, Td, H = 60, 100, 45, 7, 100
