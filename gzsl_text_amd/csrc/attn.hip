@@ -609,15 +609,25 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
             // K[tok = 4s + lq][e = 16j + lr]: row 4s + lq has swz = (2(s & 1) + (lq >> 1)) & 3
             const float* kq0 = Kp + lq * RSQ + 16 * j + 4 * ((lr >> 2) ^ (lq >> 1)) + (lr & 3);
             const float* kq1 = Kp + lq * RSQ + 16 * j + 4 * ((lr >> 2) ^ (2 + (lq >> 1))) + (lr & 3);
+            // operands of token group g (4 k steps) are read one group ahead of their MFMAs and pinned there
+            f32x4 af[2];
+            float kf[2][4];
+            auto ldg = [&](int g, int slot) {
+                af[slot] = ap[g];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kf[slot][i] = ((i & 1) ? kq1 : kq0)[(4 * (4 * g + i)) * RSQ];
+            };
+            ldg(0, 0);
 #pragma unroll
             for (int g = 0; g < NW; ++g) {
-                const f32x4 av = ap[g];
+                if (g + 1 < NW) ldg(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float kv = ((i & 1) ? kq1 : kq0)[(4 * (4 * g + i)) * RSQ];
-                    if (i & 1) q1 = mfma16(av[i], kv, q1);
-                    else q0 = mfma16(av[i], kv, q0);
+                    if (i & 1) q1 = mfma16(af[g & 1][i], kf[g & 1][i], q1);
+                    else q0 = mfma16(af[g & 1][i], kf[g & 1][i], q0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) dqo[(4 * lq + r) * DQW + 16 * j + lr] = q0[r] + q1[r];
