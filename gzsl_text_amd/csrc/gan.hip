@@ -40,8 +40,10 @@ __global__ void gp_slope_v_kernel(const float* __restrict__ h, const float* __re
 }
 
 __global__ void gp_rownorm_kernel(float* __restrict__ g, float* gp, int Bg, int D, float lam) {
-    const int lane = threadIdx.x & 63;
-    int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int row = blockIdx.x * (blockDim.x >> 6) + wv;
+    float part = 0.f;  // this wave's share of the penalty: one atomic per block (same-address atomics cost ~100 ns each)
     for (; row < Bg; row += gridDim.x * (blockDim.x >> 6)) {
         float ss = 0.f;
         for (int d = lane; d < D; d += 64) {
@@ -52,8 +54,11 @@ __global__ void gp_rownorm_kernel(float* __restrict__ g, float* gp, int Bg, int 
         const float nrm = sqrtf(ss);
         const float coef = nrm > 0.f ? lam * 2.f * (nrm - 1.f) / ((float)Bg * nrm) : 0.f;
         for (int d = lane; d < D; d += 64) g[(long long)row * D + d] *= coef;
-        if (lane == 0) atomicAdd(gp, lam * (nrm - 1.f) * (nrm - 1.f) / (float)Bg);
+        part += lam * (nrm - 1.f) * (nrm - 1.f) / (float)Bg;
     }
+    if (lane == 0) red[wv] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(gp, red[0] + red[1] + red[2] + red[3]);
 }
 
 __global__ void gp_dw2_kernel(const float* __restrict__ dv, const float* __restrict__ s, float* dw2, int Bg, int H,
@@ -192,7 +197,7 @@ extern "C" int gzsl_gp_slope_v(const float* h, const float* w2, float* v, float*
 
 extern "C" int gzsl_gp_rownorm(float* g, float* gp, int Bg, int D, float lam, void* stream) {
     if (Bg <= 0) return 0;
-    hipLaunchKernelGGL(gp_rownorm_kernel, dim3(ew_blocks(Bg, 4)), dim3(256), 0, ST, g, gp, Bg, D, lam);
+    hipLaunchKernelGGL(gp_rownorm_kernel, dim3(min(ew_blocks(Bg, 4), 1024)), dim3(256), 0, ST, g, gp, Bg, D, lam);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

@@ -20,6 +20,54 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a0, float 
     if (s == 123.456f) out[0] = s;
 }
 
+// phases as in the attention kernels: NM MFMAs on 13 accumulators, then NV independent VALU ops; waves/SIMD = wgs_per_cu
+template <int NM, int NV, int KIND>
+__global__ __launch_bounds__(256) void kphase(float* out, int iters, float a0, float b0) {
+    f32x4 acc[13];
+    for (int i = 0; i < 13; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a = a0 + threadIdx.x, b = b0;
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = a + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc[m % 13] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m % 13], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            if (KIND == 0) v[n % 8] = __builtin_fmaf(v[n % 8], 1.0001f, 0.5f);                         // fp32 VALU
+            if (KIND == 1) v[n % 8] = __uint_as_float((__float_as_uint(v[n % 8]) ^ 0x9E3779B1u) + 7u);  // int xor/add
+            if (KIND == 2) v[n % 8] = __uint_as_float(__float_as_uint(v[n % 8]) * 0x846ca68bu);         // v_mul_lo_u32
+            if (KIND == 3) v[n % 8] = __builtin_amdgcn_exp2f(v[n % 8]);                                 // transcendental
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 13; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int NM, int NV, int KIND>
+void runphase(int wgs_per_cu, int iters) {
+    float* out;
+    hipMalloc(&out, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    int grid = 256 * wgs_per_cu;
+    hipLaunchKernelGGL((kphase<NM, NV, KIND>), dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 2.f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kphase<NM, NV, KIND>), dim3(grid), dim3(256), 0, 0, out, iters, 1.f, 2.f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)grid * 4 * iters * NM * 2048.0;
+    printf("phases: %d MFMA + %d VALU kind %d, waves/SIMD=%d: %.3f ms  %.1f TFLOP/s\n", NM, NV, KIND, wgs_per_cu, ms, flops / ms / 1e9);
+    hipFree(out);
+}
+
 template <int NACC>
 void run(int wgs_per_cu, int iters) {
     float* out;
@@ -49,5 +97,14 @@ int main() {
     run<4>(2, 40000);
     run<26>(1, 10000);
     run<13>(3, 200000);
+    runphase<189, 400, 0>(1, 2000);
+    runphase<189, 400, 0>(2, 2000);
+    runphase<189, 400, 1>(1, 2000);
+    runphase<189, 400, 1>(2, 2000);
+    runphase<189, 400, 2>(1, 2000);
+    runphase<189, 400, 2>(2, 2000);
+    runphase<189, 100, 3>(1, 2000);
+    runphase<189, 100, 3>(2, 2000);
+    runphase<189, 0, 0>(2, 2000);
     return 0;
 }
