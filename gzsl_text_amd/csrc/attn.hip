@@ -132,6 +132,9 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnF
     }
 
     const uint32_t rowkey = gz_row_key(a.seed, GZSL_STREAM_ATTN, (uint32_t)b * (uint32_t)a.L_total + (uint32_t)(a.l_offset + lbl));
+    uint32_t colmul[4];  // (4lq + r) * C: the lane's share of the dropout hash's column product
+#pragma unroll
+    for (int r = 0; r < 4; ++r) colmul[r] = (uint32_t)(4 * lq + r) * 0x85EBCA6Bu;
     f32x4 acc[NFT];
 #pragma unroll
     for (int j = 0; j < NFT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -223,7 +226,9 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnF
                 p[r] = __expf(sv[r] - m);
                 lsum += p[r];
                 if (DROP) {  // compile-time: a runtime test here splits the loop body into many basic blocks
-                    const uint32_t uu = gz_u32(rowkey, (uint32_t)(tbase + r));
+                    // gz_u32(rowkey, tbase + r) with the column product built from a lane constant and a wave-uniform
+                    // term (scalar ALU) instead of a quarter-rate vector multiply per element
+                    const uint32_t uu = gz_mix32(rowkey ^ (colmul[r] + (uint32_t)(t0 + 16 * u) * 0x85EBCA6Bu));
                     p[r] = (uu >= a.thresh) ? p[r] * a.scale : 0.f;
                 }
             }
