@@ -130,11 +130,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # GZSL_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then share devices);
+    # the measured configuration is always one rank per GPU over RCCL ('nccl' IS RCCL on ROCm)
+    backend = os.environ.get('GZSL_BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == 'nccl' else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gzsl_text_amd.modules.common_module import get_optimizer
     from tests import helpers

@@ -1,0 +1,55 @@
+"""Label-dimension sharding with the HIP kernels: two ranks share cuda:0 and talk over gloo (RCCL needs one GPU per
+rank; the driver's 8-GPU run is the RCCL path).  Every rank must reproduce the UNSHARDED golden logits / loss /
+gradients of the reference — this pins what the CPU gloo tests cannot: the kernels' global label coordinates
+(l_offset / L_total of the dropout hash), the all-gathered X||PX layout and the reduce-scattered gradients on device."""
+import os
+import sys
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.test_sharding_cpu import _free_port
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, name, train, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from tests import helpers
+        from tests.conftest import load_golden
+        from tests.golden import synth
+        g = load_golden(f"{name}_{'train' if train else 'eval'}")
+        case = synth.synth_base(**synth.BASE_CASES[name])
+        model = helpers.build_model(case, device='cuda')
+        model.enable_label_sharding()
+        helpers.check_base_against_golden(model, case, g, train, device='cuda', grad_atol=4e-6)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, 'ok'))
+    except Exception:
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize('name,world,train', [('base_gate_medium', 2, True), ('base_gate_tiny', 3, True),
+                                              ('base_gate_tiny', 2, False)])
+def test_hip_label_sharding_matches_unsharded_golden(name, world, train):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, train, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == 'ok', f'rank {rank}:\n{msg}'
