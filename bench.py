@@ -172,9 +172,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    trace = os.environ.get('GZSL_BENCH_TRACE') == '1'
+
+    def note(msg):
+        if trace:
+            print(f'[bench rank {rank}] {msg}', file=sys.stderr, flush=True)
+
+    if trace:
+        import faulthandler
+        faulthandler.dump_traceback_later(45, repeat=False, file=sys.stderr)
+    note('model built')
+    for i in range(args.warmup):
         loss = step()
+        note(f'warmup step {i} issued')
     fence()
+    note('warmup done')
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -35,6 +35,21 @@ class LabelShard:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # RCCL ('nccl') moves device tensors directly.  Under gloo (CPU tests; rehearsals with ranks sharing a GPU)
+        # device tensors are staged through host memory: gloo's own device path stalls on multi-MB tensors.
+        self.stage = dist.get_backend(group) != 'nccl'
+
+    def _run(self, fn, out, inp):
+        if self.stage and inp.is_cuda:
+            o, i = out.cpu() if out is inp else torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+            if out is inp:
+                fn(o, o)
+            else:
+                fn(o, i)
+            out.copy_(o)
+        else:
+            fn(out, inp)
+        return out
 
     def label_range(self, L):
         return partition(L, self.world, self.rank)
@@ -49,18 +64,16 @@ class LabelShard:
     def all_gather_batch(self, local):
         """[B/P, ...] on every rank -> [B, ...]."""
         out = local.new_empty((local.shape[0] * self.world,) + tuple(local.shape[1:]))
-        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
-        return out
+        return self._run(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, local.contiguous())
 
     def reduce_scatter_batch(self, full):
         """[B, ...] partial sums on every rank -> this rank's summed [B/P, ...]."""
         out = full.new_empty((full.shape[0] // self.world,) + tuple(full.shape[1:]))
-        dist.reduce_scatter_tensor(out, full.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
-        return out
+        return self._run(lambda o, i: dist.reduce_scatter_tensor(o, i, op=dist.ReduceOp.SUM, group=self.group), out,
+                         full.contiguous())
 
     def all_reduce_(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        return self._run(lambda o, i: dist.all_reduce(o, op=dist.ReduceOp.SUM, group=self.group), t, t)
 
     def all_gather_labels(self, local, L):
         """[B, L_r] column shards (uneven allowed) -> [B, L]."""
@@ -69,7 +82,7 @@ class LabelShard:
         pad = local.new_zeros((width, B))
         pad[:local.shape[1]] = local.t()
         out = local.new_empty((self.world * width, B))
-        dist.all_gather_into_tensor(out, pad, group=self.group)
+        self._run(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, pad)
         cols = []
         for r in range(self.world):
             b, e = partition(L, self.world, r)
