@@ -60,17 +60,20 @@ class _BaseModelFn(torch.autograd.Function):
         L = mod.eval_code_size
         x = x.contiguous()
         mask_c = None if mask is None else mask.contiguous().to(torch.float32)
-        avg, graph, lcache = eng.label_fwd(P, gb, keep=need_grad)
         l0, l1 = (0, L) if sh is None else sh.label_range(L)
         bs = None if sh is None else sh.batch_split(B)
         if bs is not None:
+            # this rank encodes its B/P notes; X and PX travel to every rank while the (replicated) label encoder runs
             b0, b1 = bs
             Xl, PXl, e = eng.encoder_fwd(P, x[b0:b1].contiguous(), None if mask_c is None else mask_c[b0:b1].contiguous(),
                                          seed, training, row_offset=b0 * x.shape[1])
-            XPX = sh.all_gather_batch(torch.cat([Xl, PXl], 2))
-            F_ = Xl.shape[2]
-            X, PX = XPX[:, :, :F_].contiguous(), XPX[:, :, F_:].contiguous()
+            X, hx = sh.all_gather_batch_start(Xl)
+            PX, hp = sh.all_gather_batch_start(PXl)
+            avg, graph, lcache = eng.label_fwd(P, gb, keep=need_grad)
+            hx.wait()
+            hp.wait()
         else:
+            avg, graph, lcache = eng.label_fwd(P, gb, keep=need_grad)
             X, PX, e = eng.encoder_fwd(P, x, mask_c, seed, training)
         Q = avg[l0:l1]
         clf = graph[l0:l1]
@@ -112,10 +115,14 @@ class _BaseModelFn(torch.autograd.Function):
                             davg[l0:l1])
         dgraph[l0:l1] = dclf
         if bs is not None:
+            # the partial dX / dPX of this label shard are summed and scattered over the batch while the label-side
+            # backward (independent of the encoder's) runs
             b0, b1 = bs
-            d = sh.reduce_scatter_batch(torch.cat([dX, dPX], 2))
-            F_ = X.shape[2]
-            dXl, dPXl = d[:, :, :F_].contiguous(), d[:, :, F_:].contiguous()
+            dXl, hx = sh.reduce_scatter_batch_start(dX)
+            dPXl, hp = sh.reduce_scatter_batch_start(dPX)
+            eng.label_bwd(davg, dgraph, lcache, P, gb, G)
+            hx.wait()
+            hp.wait()
             eng.encoder_bwd(dXl, dPXl, X[b0:b1], PX[b0:b1], e, x[b0:b1].contiguous(),
                             None if mask_c is None else mask_c[b0:b1].contiguous(), seed, training, P, G,
                             row_offset=b0 * x.shape[1])
@@ -130,7 +137,7 @@ class _BaseModelFn(torch.autograd.Function):
                 for k in ('emb.embed.weight', 'conv_modules.0.weight', 'conv_modules.0.bias', 'proj.weight',
                           'proj.bias'):
                     G[k].mul_(1.0 / sh.world)
-        eng.label_bwd(davg, dgraph, lcache, P, gb, G)
+            eng.label_bwd(davg, dgraph, lcache, P, gb, G)
         if sh is not None:
             sh.all_reduce_(G.flat)
         return (None, None, None, None, None) + tuple(G[k] if need else None for k, need in zip(names, ctx.needs))

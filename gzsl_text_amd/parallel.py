@@ -72,6 +72,29 @@ class LabelShard:
         return self._run(lambda o, i: dist.reduce_scatter_tensor(o, i, op=dist.ReduceOp.SUM, group=self.group), out,
                          full.contiguous())
 
+    # ---- the same two, started asynchronously (RCCL runs them on its own stream): the caller does independent work
+    # (label encoder forward / backward) and then calls .wait() on the handle, which orders the current stream after
+    # the collective.  Under gloo they run synchronously and the handle is a no-op.
+    class _Done:
+        def wait(self):
+            return None
+
+    def all_gather_batch_start(self, local):
+        out = local.new_empty((local.shape[0] * self.world,) + tuple(local.shape[1:]))
+        local = local.contiguous()
+        if self.stage:
+            self._run(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, local)
+            return out, LabelShard._Done()
+        return out, dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+
+    def reduce_scatter_batch_start(self, full):
+        out = full.new_empty((full.shape[0] // self.world,) + tuple(full.shape[1:]))
+        full = full.contiguous()
+        if self.stage:
+            self._run(lambda o, i: dist.reduce_scatter_tensor(o, i, op=dist.ReduceOp.SUM, group=self.group), out, full)
+            return out, LabelShard._Done()
+        return out, dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def all_reduce_(self, t):
         return self._run(lambda o, i: dist.all_reduce(o, op=dist.ReduceOp.SUM, group=self.group), t, t)
 
