@@ -74,6 +74,7 @@ struct Mover {
     long long rb[NS][NR];
     int orow[NS][NR];
     int kc[NS], lds_off[NS];
+    unsigned coff[NS];  // fast path: float offset of the slot from (operand base + k0 * sk); rows past the end -> row 0
     struct Tile {  // one tile's worth of this thread's slots, in flight or landed
         unsigned msk[NS][VEC ? 1 : 4];
         f32x4 v[NS];
@@ -107,6 +108,7 @@ struct Mover {
                 rb[i][e] = (long long)mbi * op.mbs;
                 // a row outside the operand gets an offset that no k can bring back into [0, span)
                 orow[i][e] = valid ? mi * op.sm + op.shift : (int)0x80000000;
+                if (e == 0) coff[i] = (unsigned)(rb[i][0] + mi * op.sm + op.shift + kc[i] * op.sk);
             }
         }
     }
@@ -147,6 +149,19 @@ struct Mover {
                 }
             }
         }
+    }
+
+    // Fast path (whole k-tile inside K, no window, no k batches): tb = operand base + k0 * sk is wave-uniform, the
+    // per-slot offset is a constant, nothing is masked.  Rows past the operand's end read row 0 instead: they only
+    // feed output rows / columns that are never stored.  (fp32 MFMA and VALU do not overlap on a SIMD, so every
+    // vector instruction of the address generation is paid in matrix time: this path has one add per slot.)
+    __device__ __forceinline__ void load_fast(const float* tb, Tile& d) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) d.v[i] = *reinterpret_cast<const f32x4*>(tb + coff[i]);
+    }
+    __device__ __forceinline__ void store_fast(float* buf, const Tile& d) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(buf + lds_off[i]) = d.v[i];
     }
 
     // the mask is applied here, after the tile's MFMAs, so that nothing waits on a load before it has to
@@ -263,12 +278,23 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
     int ki0 = kbeg - kb0 * k_inner;
     typename Mover<BM, BM, A_RC, VEC>::Tile ga;
     typename Mover<BN, BNP, B_RC, VEC>::Tile gb;
-    auto fetch = [&]() {
-        // past kend every slot is masked and its address clamped: the surplus fetch of the last iteration is harmless
+    // tiles [0, nfull) take the fast path (see Mover::load_fast); the K tail, windowed operands (conv data gradient) and
+    // k-batched operands (conv weight gradient) take the masked one
+    const bool fast = VEC && k_inner >= g.K && g.a_span == 0x7FFFFFFFu && g.a_shift == 0;
+    const int nfull = fast ? (kend - kbeg) / BK : 0;
+    bool in_regs_fast = false;  // which path fetched the tile now in registers
+    auto fetch = [&](int t) {   // tile t -> registers (t >= ntile: masked to zeros, addresses clamped: harmless)
         if (!(GZ_GEMM_ABL & 1)) {
-            ma.load(oa, k_next, kb0, ki0, kend, k_inner, ga);
-            mb.load(ob, k_next, kb0, ki0, kend, k_inner, gb);
+            if (t < nfull) {
+                const long long k0 = kbeg + (long long)t * BK;
+                ma.load_fast(oa.p + k0 * oa.sk, ga);
+                mb.load_fast(ob.p + k0 * ob.sk, gb);
+            } else {
+                ma.load(oa, k_next, kb0, ki0, kend, k_inner, ga);
+                mb.load(ob, k_next, kb0, ki0, kend, k_inner, gb);
+            }
         }
+        in_regs_fast = t < nfull;
         k_next += BK;
         ki0 += BK;
         if (ki0 >= k_inner) {
@@ -276,13 +302,22 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
             kb0 += 1;
         }
     };
-    fetch();
-    ma.store(lds, ga);
-    mb.store(lds + ASZ, gb);
+    auto stage = [&](float* buf) {  // registers -> LDS buffer
+        if (GZ_GEMM_ABL & 2) return;
+        if (in_regs_fast) {
+            ma.store_fast(buf, ga);
+            mb.store_fast(buf + ASZ, gb);
+        } else {
+            ma.store(buf, ga);
+            mb.store(buf + ASZ, gb);
+        }
+    };
+    fetch(0);
+    stage(lds);
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < ntile; ++t) {
-        fetch();                            // tile t+1 -> registers
+        fetch(t + 1);                       // tile t+1 -> registers
         __builtin_amdgcn_sched_barrier(0);  // every load is in flight before tile t's MFMAs start
         const float* abuf = lds + cur * BUF;
 #pragma unroll
@@ -304,11 +339,7 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
         }
         __builtin_amdgcn_sched_barrier(0);  // ... and nothing waits on them until the MFMAs have issued
         cur ^= 1;
-        float* nbuf = lds + cur * BUF;
-        if (!(GZ_GEMM_ABL & 2)) {
-            ma.store(nbuf, ga);
-            mb.store(nbuf + ASZ, gb);
-        }
+        stage(lds + cur * BUF);
         if (!(GZ_GEMM_ABL & 4)) __syncthreads();
     }
 
@@ -385,6 +416,12 @@ static bool vec_ok(const void* p, bool rc, int rows, int K, int mb, long long mb
                    unsigned span, int k_inner, long long kbs) {
     if (((uintptr_t)p & 15) != 0) return false;
     const bool batched_rows = mb < rows, batched_k = k_inner < K;
+    {   // the fast path keeps 32-bit element offsets: the operand's extent must stay below 2^31 floats
+        const long long nb = batched_rows ? (rows + mb - 1) / mb : 1;
+        const long long ext = nb * (mbs < 0 ? -mbs : mbs) + (long long)(batched_rows ? mb : rows) * (sm < 0 ? -sm : sm) +
+                              (long long)K * (sk < 0 ? -sk : sk);
+        if (ext >= (1ll << 31)) return false;
+    }
     if (!mult4(shift) || (span != 0x7FFFFFFFu && span != 0xFFFFFFFFu && !mult4(span))) return false;
     if (batched_rows && !mult4(mbs)) return false;
     if (batched_k && !mult4(kbs)) return false;
