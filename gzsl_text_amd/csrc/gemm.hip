@@ -345,6 +345,50 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
 
     float* C = g.C + (g.split_k > 1 ? (long long)z * g.slab_stride : 0);
     const bool plain = g.split_k > 1;
+    // Row-contiguous epilogue: the wave's 16 x (16*WTN) block goes through its private LDS rows (the k loop's last
+    // barrier has retired every read of the tile buffers) and leaves as 16-byte stores, 128 columns per pass, instead
+    // of one 4-byte store per accumulator register (4 rows x 64 B per instruction).
+    if (WTM == 1 && ((g.N | g.ldc) & 3) == 0 && (((uintptr_t)C | (uintptr_t)g.bias) & 15) == 0) {
+        constexpr int STW = 132;
+        float* st = lds + wave * (16 * STW);
+        const int rr0 = lane >> 5, c4 = (lane & 31) * 4;
+#pragma unroll
+        for (int ps = 0; ps < (16 * WTN + 127) / 128; ++ps) {
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                if (tile_row<B_RC, WTN>(j, 0) / 128 == ps) {
+                    const int c = tile_row<B_RC, WTN>(j, lr) - 128 * ps;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[(4 * lq + r) * STW + c] = acc[0][j][r];
+                }
+            }
+            const int col = n0 + 128 * ps + c4;
+            const bool col_ok = (128 * ps + c4 < 16 * WTN) && col < g.N;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!plain && g.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+#pragma unroll
+            for (int r2 = 0; r2 < 16; r2 += 2) {
+                const int rr = r2 + rr0;
+                const int row = m0 + tile_row<A_RC, 4>(wave, rr);
+                if (!col_ok || row >= g.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * STW + c4);
+                float* cp = C + (long long)row * g.ldc + col;
+                v *= g.alpha;
+                if (!plain) {
+                    v += bv;
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (g.act == GZSL_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                        else if (g.act == GZSL_ACT_TANH) v[e] = tanhf(v[e]);
+                        else if (g.act == GZSL_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(cp) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WTM; ++i) {
 #pragma unroll
@@ -447,6 +491,7 @@ static int launch_cfg(const GzslGemm& g, hipStream_t st) {
     const bool vec = vec_ok(g.A, arc, g.M, g.K, g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span, g.k_inner, g.a_kbs) &&
                      vec_ok(g.B, brc, g.N, g.K, 0x7FFFFFFF, 0, g.b_sn, g.b_sk, 0, 0xFFFFFFFFu, g.k_inner, g.b_kbs);
     size_t smem = 2 * sizeof(float) * ((arc ? BK * BM : BM * LDK) + (brc ? BK * BNP : BN * LDK) + 4 * NTHREADS);
+    if (smem < sizeof(float) * 4 * 16 * 132) smem = sizeof(float) * 4 * 16 * 132;  // the epilogue's per-wave staging rows
     dim3 grid(cdiv(g.M, BM) * cdiv(g.N, BN), 1, g.split_k > 1 ? g.split_k : 1);
 #define GZ_LAUNCH(AR, BR, V) \
     hipLaunchKernelGGL((gemm_f32_kernel<WTM, WTN, AR, BR, V>), grid, dim3(NTHREADS), smem, st, g)

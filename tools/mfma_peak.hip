@@ -68,6 +68,69 @@ void runphase(int wgs_per_cu, int iters) {
     hipFree(out);
 }
 
+// GEMM-like inner loop with nothing but LDS fragment reads, MFMAs and (optionally) a barrier:
+// 14 ds_read_b128 -> 52 MFMAs (1 x 13 tiles, 4 k steps) per iteration, as gemm_f32_kernel<1,13>.
+template <int BAR, int AHEAD>
+__global__ __launch_bounds__(256) void klds(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 272 * 16];
+    for (int i = threadIdx.x; i < 2 * 272 * 16; i += 256) lds[i] = 1.0f + (i & 7);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+    f32x4 acc[13];
+    for (int i = 0; i < 13; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto off = [&](int r, int c) { return r * 16 + 4 * (c ^ ((r >> 2) & 2)); };
+    f32x4 fa[2], fb[2][13];
+    auto ld = [&](int buf, int slot) {
+        const float* b = lds + buf * 272 * 16;
+        fa[slot] = *reinterpret_cast<const f32x4*>(b + off(16 * wave + lr, lq));
+#pragma unroll
+        for (int n = 0; n < 13; ++n) fb[slot][n] = *reinterpret_cast<const f32x4*>(b + off(64 + 16 * n + lr, lq));
+    };
+    // slots are compile-time constants (a runtime-indexed register array would live in scratch memory)
+#define KLDS_HALF(S)                                                                                          \
+    do {                                                                                                      \
+        if (AHEAD) ld(1 - S, 1 - S);                                                                          \
+        else ld(S, S);                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+            _Pragma("unroll") for (int n = 0; n < 13; ++n)                                                    \
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[S][j], fb[S][n][j], acc[n], 0, 0, 0);        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (BAR) __syncthreads();                                                                             \
+    } while (0)
+    if (AHEAD) ld(0, 0);
+    for (int it = 0; it < iters; it += 2) {
+        KLDS_HALF(0);
+        KLDS_HALF(1);
+    }
+#undef KLDS_HALF
+    float sum = 0.f;
+    for (int i = 0; i < 13; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (sum == 123.456f) out[0] = sum;
+}
+
+template <int BAR, int AHEAD>
+void runlds(int wgs_per_cu, int iters) {
+    float* out;
+    hipMalloc(&out, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    int grid = 256 * wgs_per_cu;
+    hipLaunchKernelGGL((klds<BAR, AHEAD>), dim3(grid), dim3(256), 0, 0, out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((klds<BAR, AHEAD>), dim3(grid), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)grid * 4 * iters * 52 * 2048.0;
+    printf("lds loop: 14 b128 + 52 MFMA, barrier=%d read-ahead=%d, waves/SIMD=%d: %.3f ms  %.1f TFLOP/s\n", BAR, AHEAD,
+           wgs_per_cu, ms, flops / ms / 1e9);
+    hipFree(out);
+}
+
 template <int NACC>
 void run(int wgs_per_cu, int iters) {
     float* out;
@@ -106,5 +169,10 @@ int main() {
     runphase<189, 100, 3>(1, 2000);
     runphase<189, 100, 3>(2, 2000);
     runphase<189, 0, 0>(2, 2000);
+    for (int w = 1; w <= 3; ++w) {
+        runlds<0, 0>(w, 8000);
+        runlds<1, 0>(w, 8000);
+        runlds<1, 1>(w, 8000);
+    }
     return 0;
 }
