@@ -33,9 +33,12 @@ def get_optimizer(lr, model, freeze_emb=False, opt='ADAM', weight_decay=1e-4):
             if name == 'emb.embed.weight':
                 param.requires_grad = False
                 break
-    params = filter(lambda p: p.requires_grad, model.parameters())
+    params = [p for p in model.parameters() if p.requires_grad]
     if opt == 'ADAM':
-        return optim.Adam(params, weight_decay=weight_decay, lr=lr)
+        # same update rule as the reference's optim.Adam; on device the whole parameter list is updated by one
+        # multi-tensor launch instead of ~8 elementwise passes
+        fused = len(params) > 0 and all(p.is_cuda for p in params)
+        return optim.Adam(params, weight_decay=weight_decay, lr=lr, fused=fused)
     elif opt == 'SGD':
         return optim.SGD(params, weight_decay=weight_decay, lr=lr, momentum=0.9)
     raise ValueError("optimizer is SGD or ADAM, {} not recognized!".format(opt))
