@@ -112,6 +112,19 @@ def test_embedding_scatter_grouped_by_id(ops, ref):
         assert float(dW[0].abs().sum()) == 0.0, 'padding row must get no gradient'
 
 
+def test_label_avg_bwd_repeated_words(ops, ref):
+    """Description words repeat heavily across labels (many adds into the same embedding rows)."""
+    rs = np.random.RandomState(12)
+    V, E, N, Td = 300, 100, 500, 12
+    lens = rs.randint(1, Td + 1, size=N)
+    cm = torch.from_numpy((np.arange(Td)[None] < lens[:, None]).astype(np.float32))
+    idx = torch.from_numpy(np.minimum(rs.zipf(1.4, size=(N, Td)), V - 1).astype(np.int64)) * cm.long()
+    davg = rnd(rs, N, E)
+    dW = ops.label_avg_bwd_(torch.zeros(V, E, device=DEV), g(davg), g(idx), g(cm))
+    close(dW, ref.label_avg_bwd_(torch.zeros(V, E), davg, idx, cm), 1e-5, 1e-4, 'label avg bwd (repeated words)')
+    assert float(dW[0].abs().sum()) == 0.0, 'padding row must get no gradient'
+
+
 @pytest.mark.parametrize('M,N,ld', [(20000, 200, 200), (5000, 37, 64), (300, 100, 100), (9000, 100, 300)])
 def test_colsum_workspace_and_atomic_paths(ops, M, N, ld):
     rs = np.random.RandomState(M + N)
