@@ -516,20 +516,22 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     constexpr int QPT = (BWD_BL * WQ / G + NT - 1) / NT;
     constexpr int OPT = (BWD_BL * WO / G + NT - 1) / NT;
     constexpr int DQF = (BWD_BL * DQW + NT - 1) / NT;
-    int q_row[QPT], q_col[QPT], q_lds[QPT], o_row[OPT], o_col[OPT], o_lds[OPT];
+    // global offsets are (first label of the step) * width [wave-uniform: scalar ALU] + a per-slot constant, clamped to
+    // the slot's position in the LAST label row; nothing is multiplied per step (VALU work is paid in matrix time)
+    int q_off[QPT], q_lim[QPT], q_lds[QPT], o_off[OPT], o_lim[OPT], o_lds[OPT];
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
-        const int f = (tid + NT * i) * G, r = f / WQ, c = f % WQ;
-        q_row[i] = r;
-        q_col[i] = min(c, a.E - G);
-        q_lds[i] = (r < BWD_BL) ? img_off(r, c, RSQ) : -1;
+        const int f = (tid + NT * i) * G, r = f / WQ, c = min(f % WQ, a.E - G);
+        q_off[i] = r * a.E + c;
+        q_lim[i] = (a.L - 1) * a.E + c;
+        q_lds[i] = (r < BWD_BL) ? img_off(r, f % WQ, RSQ) : -1;
     }
 #pragma unroll
     for (int i = 0; i < OPT; ++i) {
-        const int f = (tid + NT * i) * G, r = f / WO, c = f % WO;
-        o_row[i] = r;
-        o_col[i] = min(c, a.F - G);
-        o_lds[i] = (r < BWD_BL) ? img_off(r, c, RSO) : -1;
+        const int f = (tid + NT * i) * G, r = f / WO, c = min(f % WO, a.F - G);
+        o_off[i] = r * a.F + c;
+        o_lim[i] = (a.L - 1) * a.F + c;
+        o_lds[i] = (r < BWD_BL) ? img_off(r, f % WO, RSO) : -1;
     }
     vecG pq[QPT], po[OPT];
     float plse = 0.f, pdel = 0.f, plinf = 0.f;
@@ -543,13 +545,14 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     const float* delb = a.DELTA + (long long)b * a.L;
     auto prefetch = [&](int step) {
         const int l0 = step * BWD_BL;
+        const int qb = l0 * a.E, ob = l0 * a.F;
 #pragma unroll
         for (int i = 0; i < QPT; ++i)
-            pq[i] = *reinterpret_cast<const vecG*>(a.Q + (unsigned)(min(l0 + q_row[i], a.L - 1) * a.E + q_col[i]));
+            pq[i] = *reinterpret_cast<const vecG*>(a.Q + (unsigned)min(qb + q_off[i], q_lim[i]));
 #pragma unroll
         for (int i = 0; i < OPT; ++i)
-            po[i] = *reinterpret_cast<const vecG*>(dOb + (unsigned)(min(l0 + o_row[i], a.L - 1) * a.F + o_col[i]));
-        {
+            po[i] = *reinterpret_cast<const vecG*>(dOb + (unsigned)min(ob + o_off[i], o_lim[i]));
+        if (wave == 0) {  // lse, delta and the dropout row keys of the 16 labels: one wave's job
             const int l = l0 + (tid & (BWD_BL - 1));
             const unsigned o = (unsigned)min(l, a.L - 1);
             plse = lseb[o];
@@ -638,15 +641,22 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
             for (int r = 0; r < 4; ++r) dqo[(4 * lq + r) * DQW + 16 * j + lr] = q0[r] + q1[r];
         }
     };
+    int dq_goff[DQF], dq_row[DQF];  // per-slot constants of the dQ flush: global offset inside the 16-row block, row
+#pragma unroll
+    for (int i = 0; i < DQF; ++i) {
+        const int idx = tid + NT * i;
+        const int r = idx / DQW, c = idx % DQW;
+        const bool ok = idx < BWD_BL * DQW && c < a.E;
+        dq_goff[i] = r * a.E + c;
+        dq_row[i] = ok ? r : (1 << 30);  // never < L - l0
+    }
     auto dq_flush = [&](int buf, int l0p) {  // row-contiguous float atomics; fixed trip count, unrolled
         const float* dqo = dQs + buf * BWD_BL * DQW;
+        float* dqg = a.dQ + (long long)l0p * a.E;
+        const int nrow = a.L - l0p;
 #pragma unroll
-        for (int i = 0; i < DQF; ++i) {
-            const int idx = tid + NT * i;
-            const int r = idx / DQW, c = idx % DQW;
-            if (idx < BWD_BL * DQW && c < a.E && l0p + r < a.L)
-                atomicAdd(a.dQ + (long long)(l0p + r) * a.E + c, dqo[idx]);
-        }
+        for (int i = 0; i < DQF; ++i)
+            if (dq_row[i] < nrow) atomicAdd(dqg + dq_goff[i], dqo[tid + NT * i]);
     };
 
     int l0_p1 = 0, l0_p2 = 0;  // first labels of the previous two steps
