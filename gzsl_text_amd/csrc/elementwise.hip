@@ -198,6 +198,38 @@ __global__ void gru_gate_fwd_kernel(const float* __restrict__ gi, const float* _
     }
 }
 
+// One time step of the packed label GRU (lm_module.py:68-88, training=False): rows whose description is longer than t
+// take the GRUCell update, shorter rows keep their state (pack_padded_sequence semantics).  The pooled output is
+// maintained on the fly: max over the steps' hidden states EXCLUDING exact zeros (the reference's
+// masked_fill(outputs == 0, -inf)), or their sum (divided by the length at the last step) for 'mean'.
+// gi = x_t.W_ih^T + b_ih for step t is row b of a [Bg, T, 3H] tensor: gi + b * gi_stride.
+__global__ void gru_seq_step_kernel(const float* __restrict__ gi, long long gi_stride, const float* __restrict__ gh,
+                                    float* __restrict__ h, const float* __restrict__ mask, int T, int t,
+                                    float* __restrict__ pool, int pool_mode, int Bg, int H) {
+    const long long n = (long long)Bg * H;
+    GRID_STRIDE(i, n) {
+        const long long row = i / H;
+        const int c = (int)(i - row * H);
+        float len = 0.f;
+        for (int j = 0; j < T; ++j) len += mask[row * T + j];
+        if ((float)t < len) {
+            const float* a = gi + row * gi_stride;
+            const float* b = gh + row * 3 * H;
+            const float r = sigmoidf_(a[c] + b[c]);
+            const float z = sigmoidf_(a[H + c] + b[H + c]);
+            const float nn = tanhf(a[2 * H + c] + r * b[2 * H + c]);
+            const float hn = (1.f - z) * nn + z * h[i];
+            h[i] = hn;
+            if (pool_mode == 1) {
+                if (hn != 0.f) pool[i] = fmaxf(pool[i], hn);
+            } else if (pool_mode == 2) {
+                pool[i] += hn;
+            }
+        }
+        if (pool_mode == 2 && t == T - 1) pool[i] /= len;
+    }
+}
+
 __global__ void gru_gate_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ gi,
                                     const float* __restrict__ gh, const float* __restrict__ h, float* __restrict__ dgi,
                                     float* __restrict__ dgh, float* __restrict__ dh, int N, int H) {
@@ -487,6 +519,16 @@ extern "C" int gzsl_gru_gate_fwd(const float* gi, const float* gh, const float* 
     if (N <= 0) return 0;
     hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(ew_blocks((long long)N * H)), dim3(EW_THREADS), 0, ST, gi, gh, h, hn, N,
                        H);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_gru_seq_step(const float* gi, long long gi_stride, const float* gh, float* h, const float* mask, int T,
+                                 int t, float* pool, int pool_mode, int Bg, int H, void* stream) {
+    if (Bg <= 0) return 0;
+    if (t < 0 || t >= T || pool_mode < 0 || pool_mode > 2 || (pool_mode != 0 && pool == nullptr)) return GZSL_EINVAL;
+    hipLaunchKernelGGL(gru_seq_step_kernel, dim3(ew_blocks((long long)Bg * H)), dim3(EW_THREADS), 0, ST, gi, gi_stride, gh, h,
+                       mask, T, t, pool, pool_mode, Bg, H);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

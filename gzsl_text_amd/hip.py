@@ -45,6 +45,7 @@ _PROTOS = {
     'gzsl_spmm_csr': [c_void_p] * 7 + [c_int] * 3 + [c_void_p],
     'gzsl_gru_gate_fwd': [c_void_p] * 4 + [c_int, c_int, c_void_p],
     'gzsl_gru_gate_bwd': [c_void_p] * 7 + [c_int, c_int, c_void_p],
+    'gzsl_gru_seq_step': [c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     'gzsl_logits_fwd': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
     'gzsl_logits_bwd': [c_void_p] * 5 + [c_int] * 4 + [c_void_p],
     'gzsl_ldam_bce': [c_void_p] * 3 + [c_float, c_float] + [c_void_p] * 3 + [c_int, c_int, c_void_p],

@@ -3,8 +3,10 @@
 Adjacent to the hot path: train_gan.py calls `forward_enc` in every critic / generator
 iteration, yet the encoder's parameters receive exactly zero gradient there (labels are detached by `Variable(...)`,
 and the penalty depends on them only through LeakyReLU slopes), so with Adam they never leave their initial values.
-The GRU itself stays on stock PyTorch-ROCm (MIOpen) in this round; what the build adds is `LabelEncodingCache`, an
-exact per-label table that removes the per-iteration recompute (the dominant CPU cost of the reference's GAN step).
+What the build adds: `LabelEncodingCache`, an exact per-label table that removes the per-iteration recompute (the
+dominant CPU cost of the reference's GAN step), filled by `forward_enc_hip`: the packed GRU forward on the HIP kernels
+(embedding gather, one GEMM for all input projections, per step one GEMM + `gzsl_gru_seq_step`).  Calls that need
+autograd through the GRU (`forward_enc` itself) stay on stock PyTorch-ROCm.
 Same constructor signature, attributes and state-dict keys (`encoder.weight`, `rnn.*_l0`, `decoder.weight`).
 """
 import torch
@@ -57,15 +59,44 @@ class RNNLabelEncoder(nn.Module):
         return hn.squeeze()
 
 
+def forward_enc_hip(enc, input, input_mask, pool_mode='last', ops=None):
+    """`enc.forward_enc(input, input_mask, None, training=False, pool_mode)` (lm_module.py:68-88) without autograd, on
+    the HIP kernels.  GRU, one layer, zero initial state; descriptions are prefix-masked (mask.sum(1) = length)."""
+    if enc.rnn_type != 'GRU' or enc.nlayers != 1:
+        raise NotImplementedError('the HIP label encoder implements the drivers\' 1-layer GRU (train_gan.py:150)')
+    if ops is None:
+        from ..ops_hip import HipOps
+        ops = HipOps()
+    Bg, T = input.shape
+    mask = input_mask.contiguous().to(torch.float32)
+    W = enc.encoder.weight.detach()
+    rnn = enc.rnn
+    Wih, Whh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach()
+    bih, bhh = rnn.bias_ih_l0.detach(), rnn.bias_hh_l0.detach()
+    H = Whh.shape[1]
+    x = ops.emb_gather(W, input.contiguous(), mask, 0, 0.0)                  # [Bg, T, E] = W[ids] * mask
+    gi = ops.linear(x.view(Bg * T, x.shape[2]), Wih, bih).view(Bg, T, 3 * H)  # every step's input projection
+    h = torch.zeros((Bg, H), dtype=torch.float32, device=W.device)
+    pool = None
+    if pool_mode == 'max':
+        pool = torch.full((Bg, H), float('-inf'), dtype=torch.float32, device=W.device)
+    elif pool_mode == 'mean':
+        pool = torch.zeros((Bg, H), dtype=torch.float32, device=W.device)
+    for t in range(T):
+        gh = ops.linear(h, Whh, bhh)
+        ops.gru_seq_step_(gi, t, gh, h, mask, pool, pool_mode if pool is not None else 'last')
+    return h if pool is None else pool
+
+
 class LabelEncodingCache:
     """Exact table of `label_rnn.forward_enc(desc[:, :trunc], mask[:, :trunc], None, training=False, pool_mode)` for
     every label, filled once (in chunks) and indexed afterwards: `cache(label_indices)` equals what
     train_gan.py:179-183 / finetune.py:144-148 recompute per iteration.  Call `invalidate()` if the encoder's
     parameters are ever changed (they are not, by the drivers: SURVEY.md 8a-12)."""
 
-    def __init__(self, label_rnn, code_desc, code_mask, trunc=20, pool_mode='max', chunk=4096):
+    def __init__(self, label_rnn, code_desc, code_mask, trunc=20, pool_mode='max', chunk=4096, ops=None):
         self.rnn, self.desc, self.mask = label_rnn, code_desc[:, :trunc], code_mask[:, :trunc]
-        self.pool_mode, self.chunk, self.table = pool_mode, chunk, None
+        self.pool_mode, self.chunk, self.table, self.ops = pool_mode, chunk, None, ops
 
     def invalidate(self):
         self.table = None
@@ -74,8 +105,12 @@ class LabelEncodingCache:
     def _fill(self):
         was = self.rnn.training
         self.rnn.eval()
-        parts = [self.rnn.forward_enc(self.desc[i:i + self.chunk], self.mask[i:i + self.chunk], None, training=False,
-                                      pool_mode=self.pool_mode) for i in range(0, self.desc.shape[0], self.chunk)]
+        if self.ops is not None or self.desc.is_cuda:  # HIP packed GRU (or the test suite's injected stand-in)
+            parts = [forward_enc_hip(self.rnn, self.desc[i:i + self.chunk], self.mask[i:i + self.chunk], self.pool_mode,
+                                     self.ops) for i in range(0, self.desc.shape[0], self.chunk)]
+        else:
+            parts = [self.rnn.forward_enc(self.desc[i:i + self.chunk], self.mask[i:i + self.chunk], None, training=False,
+                                          pool_mode=self.pool_mode) for i in range(0, self.desc.shape[0], self.chunk)]
         self.table = torch.cat(parts, 0).contiguous()
         self.rnn.train(was)
 

@@ -219,6 +219,12 @@ class HipOps:
              h.shape[1])
         return dgi, dgh, dh
 
+    def gru_seq_step_(self, gi_all, t, gh, h, mask, pool, pool_mode):
+        """Step t of the packed label GRU (inference): gi_all [Bg,T,3H], gh [Bg,3H]; updates h (and pool) in place."""
+        Bg, T, H3 = gi_all.shape
+        call('gzsl_gru_seq_step', gi_all[:, t].data_ptr(), T * H3, ptr(gh), ptr(h), ptr(mask), T, t, ptr(pool),
+             {None: 0, 'last': 0, 'max': 1, 'mean': 2}[pool_mode], Bg, H3 // 3)
+
     # ------------------------------------------------------------------------------------ attention + head + loss
     def attn_fwd(self, PX, X, Q, l_offset, L_total, seed, p):
         B, Tp, E = PX.shape

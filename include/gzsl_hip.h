@@ -96,6 +96,13 @@ int gzsl_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, c
 int gzsl_gru_gate_fwd(const float* gi, const float* gh, const float* h, float* hn, int N, int H, void* stream);
 int gzsl_gru_gate_bwd(const float* dhn, const float* gi, const float* gh, const float* h, float* dgi, float* dgh,
                       float* dh, int N, int H, void* stream);
+/* One step t of the packed label GRU, inference (lm_module.py:68-88 with training=False; pack_padded_sequence /
+ * pad_packed_sequence semantics): rows with sum(mask[b,:]) > t take the GRUCell update of h in place, others keep
+ * their state.  gi row b = gi + b*gi_stride holds x_t.W_ih^T + b_ih, gh [Bg,3H] = h.W_hh^T + b_hh.  pool_mode 0: none
+ * ('last': the answer is h); 1: pool = max(pool, h_t) over non-zero h_t (caller initialises pool to -inf);
+ * 2: pool += h_t, divided by the length at t == T-1 (caller initialises to 0). */
+int gzsl_gru_seq_step(const float* gi, long long gi_stride, const float* gh, float* h, const float* mask, int T, int t,
+                      float* pool, int pool_mode, int Bg, int H, void* stream);
 
 /* ---- classifier head + loss -------------------------------------------------------------------------------------
  * icd_modules.py:177-182 (and :263-272): logits[b,l] = sum_d clf[l,d] * relu(direct[b,l,d]) */

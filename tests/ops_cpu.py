@@ -137,6 +137,17 @@ class CpuOps:
         n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
         return (1 - z) * n + z * h
 
+    def gru_seq_step_(self, gi_all, t, gh, h, mask, pool, pool_mode):
+        live = (t < mask.sum(1))[:, None]
+        hn = self.gru_gate_fwd(gi_all[:, t], gh, h)
+        h.copy_(torch.where(live, hn, h))
+        if pool_mode == 'max':
+            pool.copy_(torch.where(live & (hn != 0), torch.maximum(pool, hn), pool))
+        elif pool_mode == 'mean':
+            pool.add_(torch.where(live, hn, torch.zeros_like(hn)))
+            if t == mask.shape[1] - 1:
+                pool.div_(mask.sum(1)[:, None])
+
     def gru_gate_bwd(self, dhn, gi, gh, h):
         H = h.shape[1]
         r = torch.sigmoid(gi[:, :H] + gh[:, :H])

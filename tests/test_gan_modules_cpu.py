@@ -87,3 +87,10 @@ def test_label_rnn_mirror_and_cache_match_reference():
     cache = LabelEncodingCache(enc, ids, m, trunc=20, pool_mode='max', chunk=4)
     sel = torch.tensor([3, 0, 3, 10])
     close(cache(sel), g['pool_max'][sel.numpy()], 1e-5, 1e-6, 'cached label encoding')
+    # the packed-GRU orchestration the HIP path uses (gather, one input GEMM, per-step GEMM + masked gate/pool step)
+    from gzsl_text_amd.modules.lm_module import forward_enc_hip
+    from tests.ops_cpu import CpuOps
+    for mode in ('max', 'mean'):
+        close(forward_enc_hip(enc, ids, m, mode, CpuOps()), g['pool_' + mode], 1e-5, 1e-6, 'packed GRU steps ' + mode)
+    cache2 = LabelEncodingCache(enc, ids, m, trunc=20, pool_mode='max', chunk=4, ops=CpuOps())
+    close(cache2(sel), g['pool_max'][sel.numpy()], 1e-5, 1e-6, 'cache filled through the step kernels')

@@ -1,11 +1,13 @@
 """GPU parity of the whole base model / GAN variant: the module mirrors on cuda:0 (HIP kernels through the C ABI)
 against the golden vectors captured from the reference (tests/golden/*.npz) -- logits, loss and every gradient."""
+import numpy as np
 import pytest
 import torch
 
 from gzsl_text_amd.modules.icd_modules import ConvLabelAttnGAN
 from tests import helpers
 from tests.conftest import load_golden
+from tests.helpers import close
 from tests.golden import synth
 
 pytestmark = pytest.mark.gpu
@@ -63,3 +65,31 @@ def test_wgan_gp_step_matches_reference_golden(name):
     from gzsl_text_amd.ops_hip import HipOps
     from tests.gan_checks import run_gan_step_check
     run_gan_step_check(name, HipOps(), DEV)
+
+
+def test_label_gru_hip_matches_reference_golden():
+    """Packed label GRU (lm_module.py:68-88, training=False) on the HIP kernels and the cache filled through it."""
+    from gzsl_text_amd.modules.lm_module import LabelEncodingCache, RNNLabelEncoder, forward_enc_hip
+    g = load_golden('label_rnn_tiny')
+    enc = RNNLabelEncoder(g['word_emb'].copy())
+    for k, p in enc.rnn.named_parameters():
+        p.data.copy_(torch.from_numpy(g['rnn.' + k]))
+    enc = enc.to(DEV)
+    ids, m = torch.from_numpy(g['ids']).to(DEV), torch.from_numpy(g['mask']).to(DEV)
+    for mode in ('max', 'mean'):
+        close(forward_enc_hip(enc, ids, m, mode), g['pool_' + mode], 1e-5, 2e-6, 'HIP packed GRU ' + mode)
+    cache = LabelEncodingCache(enc, ids, m, trunc=20, pool_mode='max', chunk=4)
+    sel = torch.tensor([3, 0, 3, 10], device=DEV)
+    close(cache(sel), g['pool_max'][sel.cpu().numpy()], 1e-5, 2e-6, 'cache filled by the HIP GRU')
+    # a larger, ragged batch against the torch (MIOpen / CPU) GRU of the same module
+    rs = np.random.RandomState(3)
+    W = (rs.standard_normal((500, 200)) * 0.3).astype(np.float32)
+    W[0] = 0
+    enc2 = RNNLabelEncoder(W)
+    lens = rs.randint(1, 21, size=300)
+    mk = (np.arange(20)[None] < lens[:, None]).astype(np.float32)
+    idz = rs.randint(1, 500, size=(300, 20)) * mk.astype(np.int64)
+    with torch.no_grad():
+        want = enc2.forward_enc(torch.from_numpy(idz), torch.from_numpy(mk), None, training=False, pool_mode='max')
+    got = forward_enc_hip(enc2.to(DEV), torch.from_numpy(idz).to(DEV), torch.from_numpy(mk).to(DEV), 'max')
+    close(got, want, 1e-4, 1e-5, 'HIP packed GRU vs torch GRU (E=200, 300 ragged descriptions)')
