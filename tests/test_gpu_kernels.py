@@ -324,3 +324,56 @@ def test_gan_kernels(ops, ref):
     lbr = ref.keyword_ce_(lr2, kw_idx, kw_mask, w)
     close(lb, lbr, 1e-5, 1e-5, 'keyword CE loss')
     close(ld, lr2, 1e-5, 1e-6, 'keyword CE dlogits')
+
+
+def test_gemm_random_shapes_and_views(ops, ref):
+    """Random shapes, transposes, column slices (ldc > N, unaligned bases) and split-K sizes: every vector / scalar /
+    fast / masked path of the GEMM against torch."""
+    rs = np.random.RandomState(2024)
+    for it in range(40):
+        M, N, K = int(rs.randint(1, 400)), int(rs.randint(1, 330)), int(rs.choice([1, 3, 16, 17, 64, 100, 200, 333, 4096]))
+        if it % 5 == 0:
+            M, N, K = 4 * int(rs.randint(1, 80)), 4 * int(rs.randint(1, 80)), 4 * int(rs.randint(1, 600))
+        ta, tb = bool(rs.randint(2)), bool(rs.randint(2))
+        pad_a, pad_b = int(rs.choice([0, 0, 4, 5])), int(rs.choice([0, 0, 8, 3]))
+        A_store = rnd(rs, *((K, M + pad_a) if ta else (M, K + pad_a)))
+        B_store = rnd(rs, *((N, K + pad_b) if tb else (K, N + pad_b)))
+        A = A_store[:, pad_a:].t() if ta else A_store[:, pad_a:]
+        B = B_store[:, pad_b:].t() if tb else B_store[:, pad_b:]
+        Ad = g(A_store)[:, pad_a:].t() if ta else g(A_store)[:, pad_a:]
+        Bd = g(B_store)[:, pad_b:].t() if tb else g(B_store)[:, pad_b:]
+        bias = rnd(rs, N)
+        act = int(rs.randint(4))
+        wide, c0 = (N + 8, 4) if it % 10 == 0 else (N + 7, 3)  # aligned slice -> vector epilogue, else scalar
+        C0 = rnd(rs, M, wide)
+        out = g(C0).clone()
+        ops.mm(Ad, Bd, out=out[:, c0:c0 + N], bias=g(bias), act=act, accumulate=bool(it % 2), alpha=0.5 if it % 3 == 0 else 1.0)
+        want = C0.clone()
+        want[:, c0:c0 + N] = ref.mm(A, B, out=C0[:, c0:c0 + N].clone(), bias=bias, act=act, accumulate=bool(it % 2),
+                                  alpha=0.5 if it % 3 == 0 else 1.0)
+        close(out, want, 3e-5, 3e-5 * np.sqrt(K), f'mm case {it}: M={M} N={N} K={K} ta={ta} tb={tb} act={act}')
+
+
+def test_attention_random_shapes(ops, ref):
+    """Random (B, T', E, F, L) inside every instantiated shape class, dropout on: forward and backward against torch."""
+    rs = np.random.RandomState(77)
+    for it in range(14):
+        E = int(rs.choice([4, 8, 12, 52, 100, 104, 200]))
+        F = int(rs.choice([8, 20, 32, 36, 120, 200, 208]))
+        B, Tp, L = int(rs.randint(1, 4)), int(rs.randint(1, 200)), int(rs.randint(1, 150))
+        PX, X = torch.tanh(rnd(rs, B, Tp, E)), torch.relu(rnd(rs, B, Tp, F))
+        Q = rnd(rs, L, E, scale=0.3)
+        l_off, L_tot, seed, p = int(rs.randint(0, 9)), L + 11, int(rs.randint(1, 10000)), float(rs.choice([0.0, 0.2]))
+        O, lse = ops.attn_fwd(g(PX), g(X), g(Q), l_off, L_tot, seed, p)
+        Or, lser = ref.attn_fwd(PX, X, Q, l_off, L_tot, seed, p)
+        what = f'case {it}: B={B} Tp={Tp} E={E} F={F} L={L} p={p}'
+        close(lse, lser, 1e-5, 1e-5, 'lse ' + what)
+        close(O, Or, 2e-5, 2e-5, 'O ' + what)
+        dO = rnd(rs, B, L, F)
+        dPX, dX, dQ = torch.zeros(B, Tp, E, device=DEV), torch.zeros(B, Tp, F, device=DEV), torch.zeros(L, E, device=DEV)
+        ops.attn_bwd(g(dO), O, g(PX), g(X), g(Q), lse, l_off, L_tot, seed, p, dPX, dX, dQ)
+        dPXr, dXr, dQr = torch.zeros(B, Tp, E), torch.zeros(B, Tp, F), torch.zeros(L, E)
+        ref.attn_bwd(dO, Or, PX, X, Q, lser, l_off, L_tot, seed, p, dPXr, dXr, dQr)
+        close(dX, dXr, 1e-4, 2e-5 * np.sqrt(L), 'dX ' + what)
+        close(dPX, dPXr, 1e-4, 2e-5 * np.sqrt(L), 'dPX ' + what)
+        close(dQ, dQr, 1e-4, 2e-5 * np.sqrt(B * Tp), 'dQ ' + what)
