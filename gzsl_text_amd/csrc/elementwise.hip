@@ -542,6 +542,35 @@ extern "C" int gzsl_gru_gate_bwd(const float* dhn, const float* gi, const float*
     return 0;
 }
 
+// ---- host batching -> device, eval scoring --------------------------------------------------------------
+// utils/helper.py:117-123: the dense [B,L] multi-hot target built from each note's label list.  y is cleared by the
+// launcher; lanes run along the ragged index list, duplicates just store 1 twice.
+__global__ void multihot_kernel(const int64_t* __restrict__ idx, int W, float* __restrict__ y, int B, int L) {
+    const long long n = (long long)B * W;
+    GRID_STRIDE(i, n) {
+        const long long b = i / W;
+        const int64_t c = idx[i];
+        if (c >= 0 && c < L) y[b * L + c] = 1.f;
+    }
+}
+
+// utils/metrics.py:29,63-121 reduced to what the macro/micro accuracy, precision, recall and F1 need: per label column,
+// the number of notes with yhat&y, yhat, y, yhat|y, where yhat = round(sigmoid(logit)) (half-to-even: exactly 0.5 -> 0).
+// One thread per label, rows walked in order (a wave reads 256 consecutive bytes of a row): no atomics, exact integers.
+__global__ void eval_counts_kernel(const float* __restrict__ logits, int ldz, const float* __restrict__ y, int ldy,
+                                   int* __restrict__ counts, float* __restrict__ probs, int ldp, int B, int Lc) {
+    GRID_STRIDE(l, Lc) {
+        int tp = 0, pp = 0, pos = 0, un = 0;
+        for (int b = 0; b < B; ++b) {
+            const float p = 1.f / (1.f + expf(-logits[(long long)b * ldz + l]));
+            const int h = p > 0.5f, t = y[(long long)b * ldy + l] != 0.f;
+            tp += h & t, pp += h, pos += t, un += h | t;
+            if (probs) probs[(long long)b * ldp + l] = p;
+        }
+        counts[l] += tp, counts[Lc + l] += pp, counts[2ll * Lc + l] += pos, counts[3ll * Lc + l] += un;
+    }
+}
+
 extern "C" int gzsl_logits_fwd(const float* direct, const float* clf, float* logits, int B, int L, int D,
                                void* stream) {
     if (B <= 0 || L <= 0) return 0;
@@ -634,6 +663,25 @@ extern "C" int gzsl_colsum(const float* x, float* out, long long M, int N, int l
 extern "C" int gzsl_colsum_ws(const float* x, float* out, long long M, int N, int ld, float* work, long long work_floats,
                               void* stream) {
     return colsum_launch(x, out, M, N, ld, work, work_floats, ST);
+}
+
+extern "C" int gzsl_multihot(const int64_t* y_indices, int W, float* y, int B, int L, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    hipError_t e = hipMemsetAsync(y, 0, (size_t)B * L * sizeof(float), ST);
+    if (e != hipSuccess) return (int)e;
+    if (W <= 0) return 0;
+    hipLaunchKernelGGL(multihot_kernel, dim3(ew_blocks((long long)B * W)), dim3(EW_THREADS), 0, ST, y_indices, W, y, B, L);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_eval_counts(const float* logits, int ld_logits, const float* y, int ld_y, int* counts, float* probs,
+                                int ld_probs, int B, int Lc, void* stream) {
+    if (B <= 0 || Lc <= 0) return 0;
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(ew_blocks(Lc, 64)), dim3(64), 0, ST, logits, ld_logits, y, ld_y, counts,
+                       probs, ld_probs, B, Lc);
+    GZSL_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int gzsl_conv_weight_pack(const float* W, float* Wp, float* Wflip, int F, int E, int k, void* stream) {

@@ -54,6 +54,8 @@ _PROTOS = {
     'gzsl_act_bwd': [c_void_p, c_void_p, c_ll, c_int, c_void_p],
     'gzsl_colsum': [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p],
     'gzsl_colsum_ws': [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_ll, c_void_p],
+    'gzsl_multihot': [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p],
+    'gzsl_eval_counts': [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'gzsl_conv_weight_pack': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
     'gzsl_gp_interp': [c_void_p] * 4 + [c_int, c_int, c_void_p],
     'gzsl_gp_slope_v': [c_void_p] * 4 + [c_int, c_int, c_void_p],

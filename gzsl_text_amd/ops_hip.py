@@ -282,6 +282,29 @@ class HipOps:
              ptr(loss), ptr(dlogits), ptr(probs), B, L)
         return loss, dlogits, probs
 
+    # ------------------------------------------------------------------------------------ batching / eval scoring
+    def multihot(self, y_indices, L):
+        """[B,W] int64 label lists padded with -1 -> dense fp32 [B,L] targets (utils/helper.py:117-123)."""
+        B, W = y_indices.shape
+        y = torch.empty((B, L), dtype=torch.float32, device=y_indices.device)
+        call('gzsl_multihot', ptr(y_indices), W, ptr(y), B, L)
+        return y
+
+    def eval_counts_(self, logits, y, counts, probs=None):
+        """counts [4,Lc] int32 += per-label (yhat&y, yhat, y, yhat|y) over the rows of logits[:, :Lc] / y[:, :Lc]."""
+        B = logits.shape[0]
+        Lc = counts.shape[1]
+        assert counts.dtype == torch.int32 and counts.shape[0] == 4
+        assert logits.stride(1) == 1 and y.stride(1) == 1 and logits.shape[1] >= Lc and y.shape[1] >= Lc
+        assert logits.dtype == torch.float32 and y.dtype == torch.float32
+        if probs is not None:
+            assert probs.shape == (B, Lc) and probs.stride(1) == 1 and probs.dtype == torch.float32
+        if not logits.is_cuda:
+            raise RuntimeError('gzsl_text_amd kernels need tensors on a HIP device; there is no CPU path')
+        call('gzsl_eval_counts', logits.data_ptr(), logits.stride(0), y.data_ptr(), y.stride(0), ptr(counts),
+             None if probs is None else probs.data_ptr(), 0 if probs is None else probs.stride(0), B, Lc)
+        return counts
+
     def forward_final(self, fc, feats, labels, margin, C, scale, need_grad=True):
         Bs, D = feats.shape
         loss = torch.zeros((), dtype=torch.float32, device=feats.device)

@@ -132,6 +132,18 @@ int gzsl_colsum_ws(const float* x, float* out, long long M, int N, int ld, float
 /* conv_modules.0.weight [F,E,k] -> Wp[f][j*E+e] (forward GEMM operand) and Wflip[e][j'*F+f] = W[f][e][k-1-j'] (data grad) */
 int gzsl_conv_weight_pack(const float* W, float* Wp, float* Wflip, int F, int E, int k, void* stream);
 
+/* ---- batching and eval scoring either side of the step ---------------------------------------
+ * utils/helper.py:117-123 iterate_minibatch: y = zeros[B,L]; y[row, c_idx] = 1.  y_indices [B,W] int64 is the ragged
+ * label list of the batch padded with -1 (the reference's own y_indices, cut to the widest row); entries outside
+ * [0,L) are skipped -- the host mirror raises IndexError for them first, as numpy does. */
+int gzsl_multihot(const int64_t* y_indices, int W, float* y, int B, int L, void* stream);
+/* train_base.py:133 + utils/metrics.py:29,63-121: p = sigmoid(logits[b,l]) (written to probs [B,ld_probs] unless NULL),
+ * yhat = round(p) with numpy's half-to-even (p == 0.5 -> 0); counts [4,Lc] int32 (caller zeroes before the first batch):
+ * [0] += yhat&y, [1] += yhat, [2] += (y != 0), [3] += yhat|y over the B rows.  Every macro/micro accuracy, precision,
+ * recall and F1 of metrics.py, for any label subset, follows from these integers; the AUCs need the scores on the host. */
+int gzsl_eval_counts(const float* logits, int ld_logits, const float* y, int ld_y, int* counts, float* probs,
+                     int ld_probs, int B, int Lc, void* stream);
+
 /* ---- WGAN-GP step ---------------------------------------------------------------------------------------------
  * generative_module.py:27 interpolates = alpha*real + (1-alpha)*fake, alpha [Bg] */
 int gzsl_gp_interp(const float* real, const float* fake, const float* alpha, float* out, int Bg, int D, void* stream);

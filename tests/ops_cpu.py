@@ -203,6 +203,23 @@ class CpuOps:
         dl = ((torch.sigmoid(z) - y) * inv_b).contiguous() if need_grad else None
         return loss, dl, (torch.sigmoid(logits) if need_probs else None)
 
+    def multihot(self, y_indices, L):
+        B, W = y_indices.shape
+        y = torch.zeros(B, L)
+        for b in range(B):
+            row = y_indices[b]
+            y[b, row[(row >= 0) & (row < L)]] = 1
+        return y
+
+    def eval_counts_(self, logits, y, counts, probs=None):
+        Lc = counts.shape[1]
+        p = torch.sigmoid(logits[:, :Lc])
+        h, t = p > 0.5, y[:, :Lc] != 0
+        counts += torch.stack([(h & t).sum(0), h.sum(0), t.sum(0), (h | t).sum(0)]).to(torch.int32)
+        if probs is not None:
+            probs.copy_(p)
+        return counts
+
     def forward_final(self, fc, feats, labels, margin, C, scale, need_grad=True):
         rows = fc[labels]
         z = (rows * feats).sum(1)
