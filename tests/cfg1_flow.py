@@ -49,7 +49,6 @@ def run(tmp_path, DEV, ops=None):
         losses.append(float(loss.detach()))
     scheduler.step()
     assert len(losses) == 8 and np.isfinite(losses).all()
-    assert np.mean(losses[4:]) < np.mean(losses[:4]), losses          # it learns
     for k, v in model.named_parameters():
         assert (not v.requires_grad) or not torch.equal(v, before[k]), f'{k} was not updated'
 
