@@ -28,43 +28,46 @@ def add_emb_weight_decay(model, weight_decay, emb_weight_decay=1e-2):
 
 
 def get_optimizer(lr, model, freeze_emb=False, opt='ADAM', weight_decay=1e-4):
-    if freeze_emb:
-        for name, param in model.named_parameters():
-            if name == 'emb.embed.weight':
-                param.requires_grad = False
-                break
-    params = [p for p in model.parameters() if p.requires_grad]
-    if opt == 'ADAM':
-        # same update rule as the reference's optim.Adam; on device the whole parameter list is updated by one
-        # multi-tensor launch instead of ~8 elementwise passes
-        fused = len(params) > 0 and all(p.is_cuda for p in params)
-        return optim.Adam(params, weight_decay=weight_decay, lr=lr, fused=fused)
-    elif opt == 'SGD':
-        return optim.SGD(params, weight_decay=weight_decay, lr=lr, momentum=0.9)
-    raise ValueError("optimizer is SGD or ADAM, {} not recognized!".format(opt))
+    """common_module.py:105-119: Adam (or SGD with momentum 0.9) over the trainable parameters; `freeze_emb` pins
+    the word table first."""
+    named = dict(model.named_parameters())
+    if freeze_emb and 'emb.embed.weight' in named:
+        named['emb.embed.weight'].requires_grad = False
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    kind = str(opt).upper() if opt in ('ADAM', 'SGD') else None
+    if kind is None:
+        raise ValueError(f'optimizer is SGD or ADAM, {opt} not recognized!')
+    if kind == 'SGD':
+        return optim.SGD(trainable, lr=lr, momentum=0.9, weight_decay=weight_decay)
+    # same update rule as the reference's optim.Adam; on the device the whole parameter list is updated by one
+    # multi-tensor launch instead of ~8 elementwise passes per tensor
+    on_device = bool(trainable) and all(p.is_cuda for p in trainable)
+    return optim.Adam(trainable, lr=lr, weight_decay=weight_decay, fused=on_device)
 
 
 def get_scheduler(optimizer, num_epochs, ratios=(0.6, 0.8)):
-    milestones = [int(num_epochs * r) for r in ratios]
-    return optim.lr_scheduler.MultiStepLR(optimizer, milestones=milestones)
+    """common_module.py:122-123: step decay at the given fractions of the run."""
+    return optim.lr_scheduler.MultiStepLR(optimizer, milestones=[int(r * num_epochs) for r in ratios])
 
 
 class EmbLayer(nn.Module):
-    """Holder of the pretrained word table (common_module.py:70-88).  `forward` gathers rows with the HIP kernel."""
+    """Holder of the pretrained word table (common_module.py:70-88; state-dict key `embed.weight`, row `pad_idx` is the
+    padding row).  `forward` gathers rows with the HIP kernel."""
 
     def __init__(self, embed_size, vocab_size, pad_idx=0, use_emb=True, W=None, freeze_emb=True):
-        super(EmbLayer, self).__init__()
+        super().__init__()
         if use_emb:
-            assert W is not None
-            W = torch.from_numpy(W)
-            self.embed = nn.Embedding(W.size()[0], W.size()[1], padding_idx=pad_idx)
-            self.embed.weight.data = W.clone()
-            embed_size = W.size()[1]
+            if W is None:
+                raise AssertionError('use_emb=True needs the pretrained table W')
+            table = torch.as_tensor(W).detach().clone()
+            rows, embed_size = table.shape
+            self.embed = nn.Embedding(rows, embed_size, padding_idx=pad_idx)
+            with torch.no_grad():
+                self.embed.weight.copy_(table)
         else:
             self.embed = nn.Embedding(vocab_size + 1, embed_size, padding_idx=pad_idx)
         self.embed_size = embed_size
-        if freeze_emb:
-            self.embed.weight.requires_grad = False
+        self.embed.weight.requires_grad_(not freeze_emb)
 
     def forward(self, x):
         from ..ops_hip import HipOps
@@ -73,40 +76,38 @@ class EmbLayer(nn.Module):
 
 class AdamW(Optimizer):
     """The reference's hand-rolled AdamW (common_module.py:126-182): no bias correction, eps added to sqrt(v),
-    weight decay applied to the parameter.  One fused kernel per parameter tensor (`gzsl_adamw_nobias_step`)."""
+    weight decay applied to the parameter; per-parameter state keys `step`, `next_m`, `next_v`.  One fused kernel per
+    parameter tensor (`gzsl_adamw_nobias_step`)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), e=1e-6, weight_decay=0.0, ops=None):
-        if not 0.0 <= betas[0] < 1.0:
-            raise ValueError("Invalid beta parameter at index 0: {} - should be in [0.0, 1.0[".format(betas[0]))
-        if not 0.0 <= betas[1] < 1.0:
-            raise ValueError("Invalid beta parameter at index 1: {} - should be in [0.0, 1.0[".format(betas[1]))
-        if not e >= 0.0:
-            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
-        defaults = dict(lr=lr, betas=betas, e=e, weight_decay=weight_decay)
-        super(AdamW, self).__init__(params, defaults)
+        for which, beta in enumerate(betas):
+            if not 0.0 <= beta < 1.0:
+                raise ValueError(f'Invalid beta parameter at index {which}: {beta} - should be in [0.0, 1.0[')
+        if e < 0.0 or e != e:
+            raise ValueError(f'Invalid epsilon value: {e} - should be >= 0.0')
+        super().__init__(params, dict(lr=lr, betas=betas, e=e, weight_decay=weight_decay))
         self._ops = ops
 
+    def _moments(self, p):
+        st = self.state[p]
+        if not st:
+            st.update(step=0, next_m=torch.zeros_like(p.data), next_v=torch.zeros_like(p.data))
+        return st
+
     def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            loss = closure()
+        loss = closure() if closure is not None else None
         if self._ops is None:
             from ..ops_hip import HipOps
             self._ops = HipOps()
         for group in self.param_groups:
+            b1, b2 = group['betas']
             for p in group['params']:
                 if p.grad is None:
                     continue
-                grad = p.grad.data
-                if grad.is_sparse:
+                if p.grad.is_sparse:
                     raise RuntimeError('Adam does not support sparse gradients, please consider SparseAdam instead')
-                state = self.state[p]
-                if len(state) == 0:
-                    state['step'] = 0
-                    state['next_m'] = torch.zeros_like(p.data)
-                    state['next_v'] = torch.zeros_like(p.data)
-                beta1, beta2 = group['betas']
-                self._ops.adamw_step_(p.data, grad.contiguous(), state['next_m'], state['next_v'], group['lr'], beta1,
-                                      beta2, group['e'], group['weight_decay'])
-                state['step'] += 1
+                st = self._moments(p)
+                self._ops.adamw_step_(p.data, p.grad.data.contiguous(), st['next_m'], st['next_v'], group['lr'], b1, b2,
+                                      group['e'], group['weight_decay'])
+                st['step'] += 1
         return loss
