@@ -14,6 +14,7 @@ Extra, not in the reference:
   * `set_dropout_seed(seed)`: base seed of the counter RNG that replaces torch's dropout stream; the seed of a
     forward is base + number of training forwards so far (all ranks must use the same base).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -46,6 +47,43 @@ def _make_ops():
     return HipOps()
 
 
+class _Beside:
+    """Runs the replicated label encoder on a second HIP stream beside the note encoder (independent until the
+    attention).  The label side is a chain of small launches (spmm, N x 3H GEMMs, gate kernels) that leave most CUs
+    idle, and the note encoder's big GEMMs leave part of their last round empty: together they fill the chip.
+
+    Ordering rule that makes the caching allocator safe without record_stream: the side stream waits for the caller's
+    stream at entry (so memory it reuses is no longer read by earlier work) and the caller's stream waits for the side
+    stream at `join()` (so everything produced there is visible, and later frees are ordered after its readers)."""
+
+    _streams = {}
+
+    def __init__(self, ref_tensor):
+        self.on = ref_tensor.is_cuda and os.environ.get('GZSL_NO_SIDE_STREAM') != '1'
+        if self.on:
+            dev = ref_tensor.device
+            self.main = torch.cuda.current_stream(dev)
+            self.side = _Beside._streams.get(dev)
+            if self.side is None:
+                self.side = _Beside._streams[dev] = torch.cuda.Stream(dev)
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 class _BaseModelFn(torch.autograd.Function):
     """ConvLabelAttnModel.forward (icd_modules.py:174-186) and the backward autograd ran for it."""
 
@@ -73,8 +111,11 @@ class _BaseModelFn(torch.autograd.Function):
             hx.wait()
             hp.wait()
         else:
-            avg, graph, lcache = eng.label_fwd(P, gb, keep=need_grad)
+            beside = _Beside(x)
+            with beside:
+                avg, graph, lcache = eng.label_fwd(P, gb, keep=need_grad)
             X, PX, e = eng.encoder_fwd(P, x, mask_c, seed, training)
+            beside.join()
         Q = avg[l0:l1]
         clf = graph[l0:l1]
         O, lse, direct, logits_l = eng.head_fwd(P, X, PX, Q, clf, l0, L, seed, training)
@@ -126,18 +167,22 @@ class _BaseModelFn(torch.autograd.Function):
             eng.encoder_bwd(dXl, dPXl, X[b0:b1], PX[b0:b1], e, x[b0:b1].contiguous(),
                             None if mask_c is None else mask_c[b0:b1].contiguous(), seed, training, P, G,
                             row_offset=b0 * x.shape[1])
-        else:
-            if sh is not None:
-                # replicated encoder: sum the shards' partial dX||dPX, then every rank runs the same encoder
-                # backward; its (identical) parameter gradients must not be summed again -> scale by 1/P below
-                sh.all_reduce_(dX)
-                sh.all_reduce_(dPX)
+        elif sh is not None:
+            # replicated encoder: sum the shards' partial dX||dPX, then every rank runs the same encoder backward;
+            # its (identical) parameter gradients must not be summed again -> scale by 1/P before the label side adds
+            sh.all_reduce_(dX)
+            sh.all_reduce_(dPX)
             eng.encoder_bwd(dX, dPX, X, PX, e, x, mask_c, seed, training, P, G)
-            if sh is not None:
-                for k in ('emb.embed.weight', 'conv_modules.0.weight', 'conv_modules.0.bias', 'proj.weight',
-                          'proj.bias'):
-                    G[k].mul_(1.0 / sh.world)
+            for k in ('emb.embed.weight', 'conv_modules.0.weight', 'conv_modules.0.bias', 'proj.weight', 'proj.bias'):
+                G[k].mul_(1.0 / sh.world)
             eng.label_bwd(davg, dgraph, lcache, P, gb, G)
+        else:
+            # label-side backward beside the encoder's (both add into the word-table gradient: float atomics)
+            beside = _Beside(dX)
+            with beside:
+                eng.label_bwd(davg, dgraph, lcache, P, gb, G)
+            eng.encoder_bwd(dX, dPX, X, PX, e, x, mask_c, seed, training, P, G)
+            beside.join()
         if sh is not None:
             sh.all_reduce_(G.flat)
         return (None, None, None, None, None) + tuple(G[k] if need else None for k, need in zip(names, ctx.needs))
