@@ -101,15 +101,18 @@ class _BaseModelFn(torch.autograd.Function):
         l0, l1 = (0, L) if sh is None else sh.label_range(L)
         bs = None if sh is None else sh.batch_split(B)
         if bs is not None:
-            # this rank encodes its B/P notes; X and PX travel to every rank while the (replicated) label encoder runs
+            # this rank encodes its B/P notes; X and PX then travel to every rank
             b0, b1 = bs
+            beside = _Beside(x)
+            with beside:  # the replicated label encoder runs beside the note encoder AND the gathers
+                avg, graph, lcache = eng.label_fwd(P, gb, keep=need_grad)
             Xl, PXl, e = eng.encoder_fwd(P, x[b0:b1].contiguous(), None if mask_c is None else mask_c[b0:b1].contiguous(),
                                          seed, training, row_offset=b0 * x.shape[1])
             X, hx = sh.all_gather_batch_start(Xl)
             PX, hp = sh.all_gather_batch_start(PXl)
-            avg, graph, lcache = eng.label_fwd(P, gb, keep=need_grad)
             hx.wait()
             hp.wait()
+            beside.join()
         else:
             beside = _Beside(x)
             with beside:
@@ -156,17 +159,19 @@ class _BaseModelFn(torch.autograd.Function):
                             davg[l0:l1])
         dgraph[l0:l1] = dclf
         if bs is not None:
-            # the partial dX / dPX of this label shard are summed and scattered over the batch while the label-side
-            # backward (independent of the encoder's) runs
+            # the partial dX / dPX of this label shard are summed and scattered over the batch
             b0, b1 = bs
             dXl, hx = sh.reduce_scatter_batch_start(dX)
             dPXl, hp = sh.reduce_scatter_batch_start(dPX)
-            eng.label_bwd(davg, dgraph, lcache, P, gb, G)
+            beside = _Beside(dX)
+            with beside:  # beside the reduce-scatters and the note encoder's backward
+                eng.label_bwd(davg, dgraph, lcache, P, gb, G)
             hx.wait()
             hp.wait()
             eng.encoder_bwd(dXl, dPXl, X[b0:b1], PX[b0:b1], e, x[b0:b1].contiguous(),
                             None if mask_c is None else mask_c[b0:b1].contiguous(), seed, training, P, G,
                             row_offset=b0 * x.shape[1])
+            beside.join()
         elif sh is not None:
             # replicated encoder: sum the shards' partial dX||dPX, then every rank runs the same encoder backward;
             # its (identical) parameter gradients must not be summed again -> scale by 1/P before the label side adds
