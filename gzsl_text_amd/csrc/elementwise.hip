@@ -296,6 +296,38 @@ __global__ void dclf_kernel(const float* __restrict__ direct, const float* __res
     }
 }
 
+// Both gradients of the head in one pass over `direct` (it is 115 MB at cfg2): a thread owns four columns d of one label
+// and walks the notes in order, so dclf is summed in the same order as dclf_kernel does (bit-identical).
+__global__ void logits_bwd_fused_kernel(const float* __restrict__ direct, const float* __restrict__ clf,
+                                        const float* __restrict__ dlogits, float* __restrict__ ddirect,
+                                        float* __restrict__ dclf, int B, int L, int D4, int accumulate) {
+    const long long n = (long long)L * D4;
+    const float4* dir4 = reinterpret_cast<const float4*>(direct);
+    float4* dd4 = reinterpret_cast<float4*>(ddirect);
+    GRID_STRIDE(i, n) {
+        const int l = (int)(i / D4);
+        const float4 c = reinterpret_cast<const float4*>(clf)[i];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int b = 0; b < B; ++b) {
+            const long long at = (long long)b * n + i;
+            const float4 v = dir4[at];
+            const float g = dlogits[(long long)b * L + l];
+            float4 o;
+            o.x = v.x > 0.f ? g * c.x : 0.f, o.y = v.y > 0.f ? g * c.y : 0.f;
+            o.z = v.z > 0.f ? g * c.z : 0.f, o.w = v.w > 0.f ? g * c.w : 0.f;
+            dd4[at] = o;
+            s.x += g * fmaxf(v.x, 0.f), s.y += g * fmaxf(v.y, 0.f), s.z += g * fmaxf(v.z, 0.f), s.w += g * fmaxf(v.w, 0.f);
+        }
+        float4* out = reinterpret_cast<float4*>(dclf) + i;
+        if (accumulate) {
+            const float4 o = *out;
+            s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+        }
+        *out = s;
+    }
+}
+
 __global__ void ldam_bce_kernel(const float* __restrict__ logits, const float* __restrict__ y,
                                 const float* __restrict__ margin, float C, float inv_b, float* loss,
                                 float* __restrict__ dlogits, float* __restrict__ probs, int B, int L) {
@@ -312,7 +344,14 @@ __global__ void ldam_bce_kernel(const float* __restrict__ logits, const float* _
         if (probs) probs[i] = 1.f / (1.f + expf(-lg));
     }
     part = wave_sum(part);
-    if ((threadIdx.x & 63) == 0 && loss) atomicAdd(loss, part * inv_b);
+    __shared__ float wsum[EW_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) {  // one atomic per block, waves added in a fixed order
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+        atomicAdd(loss, t * inv_b);
+    }
 }
 
 __global__ void forward_final_kernel(const float* __restrict__ fc, const float* __restrict__ feats,
@@ -583,6 +622,13 @@ extern "C" int gzsl_logits_fwd(const float* direct, const float* clf, float* log
 extern "C" int gzsl_logits_bwd(const float* direct, const float* clf, const float* dlogits, float* ddirect,
                                float* dclf, int B, int L, int D, int accumulate_dclf, void* stream) {
     if (B <= 0 || L <= 0) return 0;
+    if (ddirect && dclf && (D & 3) == 0 &&
+        (((uintptr_t)direct | (uintptr_t)clf | (uintptr_t)ddirect | (uintptr_t)dclf) & 15) == 0) {
+        hipLaunchKernelGGL(logits_bwd_fused_kernel, dim3(ew_blocks((long long)L * (D / 4))), dim3(EW_THREADS), 0, ST, direct,
+                           clf, dlogits, ddirect, dclf, B, L, D / 4, accumulate_dclf);
+        GZSL_CHECK_LAUNCH();
+        return 0;
+    }
     if (ddirect) {
         hipLaunchKernelGGL(logits_bwd_kernel, dim3(ew_blocks((long long)B * L * D)), dim3(EW_THREADS), 0, ST, direct, clf,
                            dlogits, ddirect, B, L, D);

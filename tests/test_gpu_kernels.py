@@ -377,3 +377,28 @@ def test_attention_random_shapes(ops, ref):
         close(dX, dXr, 1e-4, 2e-5 * np.sqrt(L), 'dX ' + what)
         close(dPX, dPXr, 1e-4, 2e-5 * np.sqrt(L), 'dPX ' + what)
         close(dQ, dQr, 1e-4, 2e-5 * np.sqrt(B * Tp), 'dQ ' + what)
+
+
+@pytest.mark.parametrize('B,L,D', [(16, 300, 200), (3, 41, 6), (1, 5, 8), (7, 130, 52)])
+def test_logits_bwd_fused_and_fallback_paths(ops, ref, B, L, D):
+    """D % 4 == 0 takes the one-pass kernel (both gradients from one read of `direct`), otherwise the two scalar kernels;
+    need_ddirect=False (GAN model: only the classifier rows train) takes the dclf kernel alone."""
+    rs = np.random.RandomState(B * 1000 + L + D)
+    direct, clf, dl = rnd(rs, B, L, D), rnd(rs, L, D, scale=0.2), rnd(rs, B, L, scale=0.1)
+    dd, dclf = ops.logits_bwd(g(direct), g(clf), g(dl))
+    ddr, dclfr = ref.logits_bwd(direct, clf, dl)
+    close(dd, ddr, 1e-6, 1e-7, 'ddirect')
+    close(dclf, dclfr, 1e-5, 1e-6, 'dclf')
+    none, dclf2 = ops.logits_bwd(g(direct), g(clf), g(dl), need_ddirect=False)
+    assert none is None and torch.equal(dclf2, dclf)   # same summation order over the notes in both kernels
+
+
+def test_ldam_bce_many_blocks(ops, ref):
+    rs = np.random.RandomState(12)
+    B, L = 16, 9000
+    logits, y = rnd(rs, B, L, scale=3.0), torch.from_numpy((rs.random_sample((B, L)) < 0.002).astype(np.float32))
+    margin = torch.from_numpy(rs.uniform(0.2, 1.0, L).astype(np.float32))
+    loss, dl, _ = ops.ldam_bce(g(logits), g(y), g(margin), 2.0, 1.0 / B)
+    lossr, dlr, _ = ref.ldam_bce(logits, y, margin, 2.0, 1.0 / B)
+    close(loss, lossr, 2e-6, 1e-3, 'ldam bce loss over 563 blocks')
+    close(dl, dlr, 1e-5, 1e-7, 'dlogits')
