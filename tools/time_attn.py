@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gzsl_text_amd.ops_hip import HipOps  # noqa: E402
 
 
-def timed(fn, n=5):
+def timed(fn, n=int(os.environ.get('N_IT', 5))):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -33,7 +33,7 @@ def main():
         O, lse = ops.attn_fwd(PX, X, Q, 0, L, 1, p)
         dPX, dX, dQ = torch.zeros_like(PX), torch.zeros_like(X), torch.zeros_like(Q)
         tf = timed(lambda: ops.attn_fwd(PX, X, Q, 0, L, 1, p))
-        tb = timed(lambda: ops.attn_bwd(dO, O, PX, X, Q, lse, 0, L, 1, p, dPX, dX, dQ))
+        tb = 0.0 if os.environ.get('FWD_ONLY') else timed(lambda: ops.attn_bwd(dO, O, PX, X, Q, lse, 0, L, 1, p, dPX, dX, dQ))
         print(f'p={p}: fwd {tf:.3f} ms, bwd (delta + main) {tb:.3f} ms', flush=True)
 
 
