@@ -147,15 +147,29 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnF
     // global -> registers; stays in flight while the previous tile is computed.  Clamped addresses, no validity
     // selects (a `cond ? load : 0` makes hipcc branch around the load and wait inside the branch): rows past Tp hold
     // finite neighbouring data whose scores are masked to -inf below, so their P is exactly 0.
+    // element offsets of this thread's loads inside a FULL tile: loop-invariant, so the steady state is a wave-uniform
+    // base (scalar registers) + one 32-bit lane offset per load, no per-tile address arithmetic on the vector ALU
+    unsigned kgo[NKL], vgo[NVL];
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) kgo[i] = (unsigned)min((tid + NT * i) * G, FWD_BT * a.E - G);
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) vgo[i] = (unsigned)min((tid + NT * i) * G, FWD_BT * a.F - G);
     auto issue = [&](int t0) {
-        const int rows = min(FWD_BT, a.Tp - t0);
-        const int nk = rows * a.E, nv = rows * a.F;
         const float* kb = PXb + (long long)t0 * a.E;
         const float* vb = Xb + (long long)t0 * a.F;
+        if (t0 + FWD_BT <= a.Tp) {
 #pragma unroll
-        for (int i = 0; i < NKL; ++i) kreg[i] = *reinterpret_cast<const vecG*>(kb + min((tid + NT * i) * G, nk - G));
+            for (int i = 0; i < NKL; ++i) kreg[i] = *reinterpret_cast<const vecG*>(kb + kgo[i]);
 #pragma unroll
-        for (int i = 0; i < NVL; ++i) vreg[i] = *reinterpret_cast<const vecG*>(vb + min((tid + NT * i) * G, nv - G));
+            for (int i = 0; i < NVL; ++i) vreg[i] = *reinterpret_cast<const vecG*>(vb + vgo[i]);
+        } else {  // last, partial tile of the note
+            const int rows = a.Tp - t0;
+            const int nk = rows * a.E, nv = rows * a.F;
+#pragma unroll
+            for (int i = 0; i < NKL; ++i) kreg[i] = *reinterpret_cast<const vecG*>(kb + min((tid + NT * i) * G, nk - G));
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) vreg[i] = *reinterpret_cast<const vecG*>(vb + min((tid + NT * i) * G, nv - G));
+        }
     };
     auto commit = [&]() {  // registers -> LDS (one 16-byte store per load when G == 4)
 #pragma unroll
