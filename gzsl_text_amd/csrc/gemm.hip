@@ -525,9 +525,24 @@ extern "C" int gzsl_gemm(const GzslGemm* gp, void* stream) {
         if (g.k_per_split <= 0 || g.k_per_split % BK != 0) return GZSL_EINVAL;
         if ((long long)g.k_per_split * g.split_k < g.K) return GZSL_EINVAL;
     }
-    // tile width: the one whose padded N wastes least MFMA work (ties -> wider tile)
-    const int pad128 = cdiv(g.N, 128) * 128, pad208 = cdiv(g.N, 208) * 208, pad112 = cdiv(g.N, 112) * 112;
-    const int wn = (pad208 < pad128 && pad208 <= pad112) ? 13 : (pad112 < pad128 ? 7 : 8);
+    // tile width: 208, 128 or 112 columns.  Cost model fitted to tools/sweep_gemm_wn.py on MI355X: a CU's time is
+    // (workgroups it receives) x (tile width), divided by a throughput factor that says how well 1 / 2 / >= 3
+    // co-resident workgroups keep its matrix pipes busy.  On deep grids this is "least padded N"; on shallow ones
+    // (GAN MLPs at Bg = 4096, the N-node GRU GEMMs) it prefers narrower tiles that reach every CU (up to 1.5x).
+    int wn = 13;
+    {
+        const long rows = (long)cdiv(g.M, 64) * (g.split_k > 1 ? g.split_k : 1);
+        float best = 0.f;
+        const int cand[3] = {13, 8, 7};  // ties -> wider tile (fewer re-reads of the B operand)
+        for (int c = 0; c < 3; ++c) {
+            const long per_cu = (rows * cdiv(g.N, 16 * cand[c]) + 255) / 256;
+            const float thr = per_cu >= 3 ? 1.0f : (per_cu == 2 ? 0.95f : 0.88f);
+            const float cost = (float)per_cu * cand[c] / thr;
+            if (c == 0 || cost < best * 0.995f) best = cost, wn = cand[c];
+        }
+    }
+    static const int force_wn = env_int("GZSL_GEMM_WN", 0);  // diagnostic override: 13, 7 or 8
+    if (force_wn == 13 || force_wn == 7 || force_wn == 8) wn = force_wn;
     // tile height: 128 rows once the grid is deep enough that the last round does not matter, else 64
     static const int force_wtm = env_int("GZSL_GEMM_WTM", 0);
     const long tiles64 = (long)cdiv(g.M, 64) * cdiv(g.N, 16 * wn) * (g.split_k > 1 ? g.split_k : 1);
