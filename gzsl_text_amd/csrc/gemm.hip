@@ -525,17 +525,19 @@ extern "C" int gzsl_gemm(const GzslGemm* gp, void* stream) {
         if (g.k_per_split <= 0 || g.k_per_split % BK != 0) return GZSL_EINVAL;
         if ((long long)g.k_per_split * g.split_k < g.K) return GZSL_EINVAL;
     }
-    // tile width: 208, 128 or 112 columns.  Cost model fitted to tools/sweep_gemm_wn.py on MI355X: a CU's time is
-    // (workgroups it receives) x (tile width), divided by a throughput factor that says how well 1 / 2 / >= 3
-    // co-resident workgroups keep its matrix pipes busy.  On deep grids this is "least padded N"; on shallow ones
-    // (GAN MLPs at Bg = 4096, the N-node GRU GEMMs) it prefers narrower tiles that reach every CU (up to 1.5x).
-    int wn = 13;
-    {
-        const long rows = (long)cdiv(g.M, 64) * (g.split_k > 1 ? g.split_k : 1);
+    // tile width: the one whose padded N wastes least MFMA work (ties -> wider tile) ...
+    const int pad128 = cdiv(g.N, 128) * 128, pad208 = cdiv(g.N, 208) * 208, pad112 = cdiv(g.N, 112) * 112;
+    int wn = (pad208 < pad128 && pad208 <= pad112) ? 13 : (pad112 < pad128 ? 7 : 8);
+    // ... unless the grid is too shallow to reach every CU twice (GAN MLPs at Bg = 4096, small label graphs): then a cost
+    // model fitted to tools/sweep_gemm_wn.py picks the width.  A CU's time is (workgroups it receives) x (tile width)
+    // over a throughput factor for 1 / 2 / >= 3 co-resident workgroups; narrower tiles win up to 1.5x there.  Deep
+    // and split-K grids keep the padding rule (inside the train step the narrow tiles measured slower).
+    const long rows64 = cdiv(g.M, 64);
+    if (g.split_k <= 1 && rows64 * cdiv(g.N, 16 * wn) < 512) {
         float best = 0.f;
-        const int cand[3] = {13, 8, 7};  // ties -> wider tile (fewer re-reads of the B operand)
+        const int cand[3] = {13, 8, 7};
         for (int c = 0; c < 3; ++c) {
-            const long per_cu = (rows * cdiv(g.N, 16 * cand[c]) + 255) / 256;
+            const long per_cu = (rows64 * cdiv(g.N, 16 * cand[c]) + 255) / 256;
             const float thr = per_cu >= 3 ? 1.0f : (per_cu == 2 ? 0.95f : 0.88f);
             const float cost = (float)per_cu * cand[c] / thr;
             if (c == 0 || cost < best * 0.995f) best = cost, wn = cand[c];
