@@ -137,7 +137,10 @@ def main():
     dev_index = local_rank if backend == 'nccl' else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    # GZSL_BENCH_FORCE_DIST=1 (under torchrun --nproc-per-node 1) takes the distributed code path with ONE rank: a
+    # rehearsal of the RCCL calls on a one-GPU box
+    dist_on = world > 1 or os.environ.get('GZSL_BENCH_FORCE_DIST') == '1'
+    if dist_on:
         import torch.distributed as dist
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
@@ -152,7 +155,7 @@ def main():
     model = helpers.build_model(case, device=dev)
     model.train()
     model.set_dropout_seed(1234)
-    if world > 1:
+    if dist_on:
         model.enable_label_sharding()
     x, y, mask = helpers.batch_tensors(case, dev)
     opt = get_optimizer(1e-3, model, weight_decay=1e-5)
@@ -168,7 +171,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -194,7 +197,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -232,7 +235,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(case, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

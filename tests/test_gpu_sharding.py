@@ -17,12 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, name, train, q):
+def _worker(rank, world, port, name, train, q, backend='gloo'):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         torch.cuda.set_device(0)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
         from tests import helpers
         from tests.conftest import load_golden
         from tests.golden import synth
@@ -53,3 +56,18 @@ def test_hip_label_sharding_matches_unsharded_golden(name, world, train):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == 'ok', f'rank {rank}:\n{msg}'
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_rccl_backend_single_rank(train):
+    """The code path the 8-GPU run takes ('nccl' = RCCL: device tensors handed to the collectives directly, all-gathers
+    and reduce-scatters started with async_op=True and waited on, second-stream label encoder beside them), on the one
+    GPU a test box has: a process group of ONE rank.  Catches misuse of the RCCL API (layouts, dtypes, handles, stream
+    ordering); the multi-rank arithmetic is pinned by the gloo tests above."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), 'base_gate_medium', train, q, 'nccl'))
+    p.start()
+    rank, msg = q.get(timeout=200)
+    p.join(timeout=60)
+    assert msg == 'ok', msg
