@@ -17,6 +17,7 @@
 // exponentiated tile is already the B operand of  O^T += V^T . P^T  -- no LDS round trip, no transpose.
 // Backward puts TOKENS on the lane axis (a workgroup owns 128 tokens and sweeps the labels), so S and dP tiles are
 // directly the B operands of dV^T += dO^T . Pd and dK^T += Q^T . dS; only dS crosses LDS once (per wave) for dQ.
+#include <type_traits>
 #include "common.h"
 #include "rng.h"
 #include "../../include/gzsl_hip.h"
@@ -387,8 +388,9 @@ __device__ __forceinline__ int grp_col(int j, int i) {
 //   "along rows": lane (lr, lq) reads row 4lq + r, columns grp_col(4jg.., lr) = the B operands of FOUR accumulator tiles
 //                 for k step r (dK += dS^T.Q and dV += Pd^T.dO, whose A operands dS / Pd are the S-tile registers).
 // Nothing is stored twice and nothing is transposed through LDS except dS, once per step, for dQ.
-template <int ES, int NFT, int NW>
+template <int ES, int NFT, int NW, bool PAIR = false>
 struct BwdLds {
+    static constexpr int NWV = PAIR ? 2 * NW : NW;  // waves in the workgroup (PAIR: a K-role and a V-role wave per token group)
     static constexpr int NET = (4 * ES + 15) / 16;  // 16-wide tiles over E
     static constexpr int NG = ES / 4;               // whole 4-step groups over e (S)
     static constexpr int REM = ES % 4;              // leftover steps of S: e = 16*NG + 4*j + lq
@@ -406,9 +408,10 @@ struct BwdLds {
     static constexpr int oDS = oAux + 2 * 48;             // [2][16][RSD]    dS of the workgroup's tokens
     static constexpr int odQ = oDS + 2 * BWD_BL * RSD;    // [2][16][DQW]    dQ tiles awaiting their flush
     static constexpr int oKp = odQ + 2 * BWD_BL * DQW;    // [NW*16][RSQ]    this workgroup's keys
-    static constexpr int total = oKp + NW * 16 * RSQ;
+    static constexpr int oXch = oKp + NW * 16 * RSQ;      // [2][NW][64][4]  PAIR only: Pd and dP tiles exchanged by a wave pair
+    static constexpr int total = oXch + (PAIR ? 2 * NW * 256 : 0);
     static constexpr int STW = 129;                       // epilogue staging row: 128 columns per pass, odd stride
-    static constexpr int stage = NW * 16 * STW;           // (aliases the front)
+    static constexpr int stage = NWV * 16 * STW;          // (aliases the front)
     static constexpr int floats = total > stage ? total : stage;
 };
 
@@ -419,8 +422,8 @@ __device__ __forceinline__ int img_off(int row, int col, int RS) { return row * 
 // Accumulator tiles hold [token 4*lq + r][column grp_col(j, lr)].  Stage 128 columns at a time as [token][column] in the
 // wave's private LDS rows and add whole token rows to global memory (256 contiguous bytes per wave-instruction: the
 // shape float atomics run at full rate in).  All indices are compile-time after unrolling (no scratch).
-template <int NTILES, int STW>
-__device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NTILES], float* st, int lane, int tok0, int Tp,
+template <int NTILES, int STW, int NARR>
+__device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NARR], float* st, int lane, int tok0, int Tp,
                                            int width, float* out, int ld) {
     const int lr = lane & 15, lq = lane >> 4;
     constexpr int NPASS = (16 * NTILES + 127) / 128;
@@ -447,12 +450,19 @@ __device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NTILES], float* 
 }
 
 // G = floats per staging load (4 when E and F are multiples of 4)
-template <int ES, int NFT, int NW, int G>
-__global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) {
-    using P = BwdLds<ES, NFT, NW>;
+//
+// PAIR (E > 100): a token's state is K, V, dK, dV = 4(E+F) floats; with one wave owning all of it a 64-token workgroup
+// fills the register file at ONE wave per SIMD.  Instead two waves share each group of 16 tokens: the K-role wave
+// computes S = Q.K^T, P, the dropout mask and dK, the V-role wave dP = dO.V^T and dV.  They exchange the 16x16 Pd and
+// dP tiles (same lane layout: one 16-byte LDS store and load per lane) across one extra barrier per step; each
+// holds ONE accumulator array, so the workgroup runs 8 waves = two per SIMD.
+template <int ES, int NFT, int NW, int G, bool PAIR>
+__global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) {
+    using P = BwdLds<ES, NFT, NW, PAIR>;
+    constexpr int NWV = P::NWV;
     constexpr int NET = P::NET, NG = P::NG, REM = P::REM, FS = P::FS, RSQ = P::RSQ, RSO = P::RSO, DQW = P::DQW;
     constexpr int RSD = P::RSD, KSD = P::KSD, TQ = P::TQ, TSZ = P::TSZ;
-    constexpr int NT = NW * 64;
+    constexpr int NT = NWV * 64;
     constexpr int WQ = 4 * ES, WO = 16 * NFT;  // staged tile widths (compile-time; columns past E / F are clamped copies)
     typedef float vecG __attribute__((ext_vector_type(G)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -464,7 +474,11 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     float* dQs = sm + P::odQ;
     float* Kp = sm + P::oKp;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wave = PAIR ? (wv & (NW - 1)) : wv;   // token group of this wave
+    const bool role_v = PAIR && wv >= NW;           // PAIR: waves [NW, 2NW) hold V / dV, waves [0, NW) hold K / dK
+    const bool do_k = !PAIR || !role_v, do_v = !PAIR || role_v;
+    static_assert(!PAIR || (NW & (NW - 1)) == 0, "PAIR needs a power-of-two token-wave count");
     const int lr = lane & 15, lq = lane >> 4;
     const int nTT = (a.Tp + 16 * NW - 1) / (16 * NW);
     int b, tt, sp;
@@ -514,7 +528,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     // values stay in registers, B operand of dP = dO.V^T in the k order of the "along k" reads:
     //   vT[4g + j] = V[tok][16g + 4lq + j]   (mask by multiply: loads stay unconditional)
     float vT[FS];
-    {
+    if (do_v) {
         const float* vrow = Xb + (long long)min(tok, a.Tp - 1) * a.F;
 #pragma unroll
         for (int s = 0; s < FS; ++s) {
@@ -523,11 +537,15 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
         }
     }
 
-    f32x4 dK[NET], dV[NFT];  // [token 4lq + r][column grp_col(j, lr)]
+    // [token 4lq + r][column grp_col(j, lr)].  PAIR: one array per wave, dK tiles in the K-role wave, dV tiles in the other
+    constexpr int NACC = NET > NFT ? NET : NFT;
+    f32x4 dK[PAIR ? 1 : NET], dV[PAIR ? 1 : NFT], acc[PAIR ? NACC : 1];
 #pragma unroll
-    for (int j = 0; j < NET; ++j) dK[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < (PAIR ? 1 : NET); ++j) dK[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < NFT; ++j) dV[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < (PAIR ? 1 : NFT); ++j) dV[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (PAIR ? NACC : 1); ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const uint32_t seedmix = gz_mix32(a.seed + GZSL_STREAM_ATTN * 0x632BE5ABu);
     const uint32_t rowbase = (uint32_t)b * (uint32_t)a.L_total + (uint32_t)a.l_offset;
@@ -573,7 +591,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
 #pragma unroll
         for (int i = 0; i < OPT; ++i)
             po[i] = *reinterpret_cast<const vecG*>(dOb + (unsigned)min(ob + o_off[i], o_lim[i]));
-        if (wave == 0) {  // lse, delta and the dropout row keys of the 16 labels: one wave's job
+        if (wv == 0) {  // lse, delta and the dropout row keys of the 16 labels: one wave's job
             const int l = l0 + (tid & (BWD_BL - 1));
             const unsigned o = (unsigned)min(l, a.L - 1);
             plse = lseb[o];
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     auto dq_tile = [&](int buf) {
         const float* dsp = dSs + buf * BWD_BL * RSD;
         float* dqo = dQs + buf * BWD_BL * DQW;
-        for (int j = wave; j < NET; j += NW) {
+        for (int j = wv; j < NET; j += NWV) {
             f32x4 q0 = f32x4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
             const f32x4* ap = reinterpret_cast<const f32x4*>(dsp + lr * RSD + lq * KSD);  // dS[label lr][tok 4s+lq]
             // K[tok = 4s + lq][e = 16j + lr]: row 4s + lq has swz = (2(s & 1) + (lq >> 1)) & 3
@@ -714,36 +732,78 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
                 rq[j] = qp[xrem[j]];
                 rk[j] = Kw[xrem[j]];
             }
-            ld(0, 0);
+            auto run_items = [&](auto I0, auto I1) {
+                constexpr int i0 = decltype(I0)::value, i1 = decltype(I1)::value;
+                if constexpr (i0 < i1) {
+                    ld(i0, i0 & 1);
 #pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                if (it + 1 < NI) ld(it + 1, (it + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 av = fa[it & 1];
-                if (it < NG) {
-                    const f32x4 bv = fb[it & 1];
+                    for (int it = i0; it < i1; ++it) {
+                        if (it + 1 < i1) ld(it + 1, (it + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f32x4 av = fa[it & 1];
+                        if (it < NG) {
+                            const f32x4 bv = fb[it & 1];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (i & 1) s1 = mfma16(av[i], bv[i], s1);
-                        else s0 = mfma16(av[i], bv[i], s0);
-                    }
-                    if (it == NG - 1) {
+                            for (int i = 0; i < 4; ++i) {
+                                if (i & 1) s1 = mfma16(av[i], bv[i], s1);
+                                else s0 = mfma16(av[i], bv[i], s0);
+                            }
+                            if (it == NG - 1) {
 #pragma unroll
-                        for (int j = 0; j < REM; ++j) {
-                            if (j & 1) s1 = mfma16(rq[j], rk[j], s1);
-                            else s0 = mfma16(rq[j], rk[j], s0);
+                                for (int j = 0; j < REM; ++j) {
+                                    if (j & 1) s1 = mfma16(rq[j], rk[j], s1);
+                                    else s0 = mfma16(rq[j], rk[j], s0);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (i & 1) d1 = mfma16(av[i], vT[4 * (it - NG) + i], d1);
+                                else d0 = mfma16(av[i], vT[4 * (it - NG) + i], d0);
+                            }
                         }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (i & 1) d1 = mfma16(av[i], vT[4 * (it - NG) + i], d1);
-                        else d0 = mfma16(av[i], vT[4 * (it - NG) + i], d0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            using IC0 = std::integral_constant<int, 0>;
+            using ICG = std::integral_constant<int, NG>;
+            using ICI = std::integral_constant<int, NI>;
+            if constexpr (!PAIR) {
+                ld(0, 0);
+#pragma unroll
+                for (int it = 0; it < NI; ++it) {
+                    if (it + 1 < NI) ld(it + 1, (it + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x4 av = fa[it & 1];
+                    if (it < NG) {
+                        const f32x4 bv = fb[it & 1];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (i & 1) s1 = mfma16(av[i], bv[i], s1);
+                            else s0 = mfma16(av[i], bv[i], s0);
+                        }
+                        if (it == NG - 1) {
+#pragma unroll
+                            for (int j = 0; j < REM; ++j) {
+                                if (j & 1) s1 = mfma16(rq[j], rk[j], s1);
+                                else s0 = mfma16(rq[j], rk[j], s0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (i & 1) d1 = mfma16(av[i], vT[4 * (it - NG) + i], d1);
+                            else d0 = mfma16(av[i], vT[4 * (it - NG) + i], d0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                if (role_v) run_items(ICG{}, ICI{});
+                else run_items(IC0{}, ICG{});
             }
-            if (NG == 0) {
+            if (NG == 0 && do_k) {
 #pragma unroll
                 for (int j = 0; j < REM; ++j) {
                     if (j & 1) s1 = mfma16(rq[j], rk[j], s1);
@@ -751,73 +811,162 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
                 }
             }
         }
-        float pd[4], ds[4];
-        {
-            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(ax + 4 * lq);
-            const f32x4 del4 = *reinterpret_cast<const f32x4*>(ax + 16 + 4 * lq);
-            const f32x4 key4 = *reinterpret_cast<const f32x4*>(ax + 32 + 4 * lq);
+        if constexpr (!PAIR) {
+            float pd[4], ds[4];
+            {
+                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(ax + 4 * lq);
+                const f32x4 del4 = *reinterpret_cast<const f32x4*>(ax + 16 + 4 * lq);
+                const f32x4 key4 = *reinterpret_cast<const f32x4*>(ax + 32 + 4 * lq);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
-                float dsc = 1.f;
-                if (a.thresh && !(GZ_ABL & 4))
-                    dsc = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
-                pd[r] = p * dsc;
-                ds[r] = p * ((d0[r] + d1[r]) * dsc - del4[r]);
+                for (int r = 0; r < 4; ++r) {
+                    float p = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
+                    float dsc = 1.f;
+                    if (a.thresh && !(GZ_ABL & 4))
+                        dsc = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
+                    pd[r] = p * dsc;
+                    ds[r] = p * ((d0[r] + d1[r]) * dsc - del4[r]);
+                }
             }
-        }
-        // publish this wave's dS block (label 4lq + r, token 16*wave + lr) into the step's dS tile
-        {
-            float* dw = dSs + cur * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * KSD + 4 * wave + (lr >> 2);
+            // publish this wave's dS block (label 4lq + r, token 16*wave + lr) into the step's dS tile
+            {
+                float* dw = dSs + cur * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * KSD + 4 * wave + (lr >> 2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dw[r * RSD] = ds[r];
-        }
-        // dV[tok, f] += sum_l Pd[l, tok] dO[l, f] ;  dK[tok, e] += sum_l dS[l, tok] Q[l, e].  k step r pairs labels
-        // {4q + r}: A = pd[r] / ds[r] straight from the S-tile registers, B = row 4lq + r of the dO / Q image.
-        if (!(GZ_ABL & 2)) {
+                for (int r = 0; r < 4; ++r) dw[r * RSD] = ds[r];
+            }
+            // dV[tok, f] += sum_l Pd[l, tok] dO[l, f] ;  dK[tok, e] += sum_l dS[l, tok] Q[l, e].  k step r pairs labels
+            // {4q + r}: A = pd[r] / ds[r] straight from the S-tile registers, B = row 4lq + r of the dO / Q image.
+            if (!(GZ_ABL & 2)) {
+                constexpr int FG4 = NFT / 4 * 4, EG4 = NET / 4 * 4;
+                constexpr bool F2 = (NFT - FG4) >= 2, F1 = ((NFT - FG4) & 1) != 0;
+                constexpr bool E2 = (NET - EG4) >= 2, E1 = ((NET - EG4) & 1) != 0;
+                // B fragments of k step r: one float per accumulator tile, read one k step ahead of its MFMAs
+                float bo[2][NFT], bq[2][NET];
+                auto ldrow = [&](int r, int slot) {
+                    const float* orow = to + (4 * lq + r) * RSO;
+                    const float* qrow = tq + (4 * lq + r) * RSQ;
+#pragma unroll
+                    for (int jg = 0; jg < NFT / 4; ++jg) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(orow + 64 * jg + x4[r >> 1]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bo[slot][4 * jg + e] = v4[e];
+                    }
+                    if (F2) {
+                        const f32x2 v2 = *reinterpret_cast<const f32x2*>(orow + 16 * FG4 + x2[r >> 1]);
+                        bo[slot][FG4] = v2[0];
+                        bo[slot][FG4 + 1] = v2[1];
+                    }
+                    if (F1) bo[slot][NFT - 1] = orow[16 * (FG4 + (F2 ? 2 : 0)) + x1[r >> 1]];
+#pragma unroll
+                    for (int jg = 0; jg < NET / 4; ++jg) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(qrow + 64 * jg + x4[r >> 1]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bq[slot][4 * jg + e] = v4[e];
+                    }
+                    if (E2) {
+                        const f32x2 v2 = *reinterpret_cast<const f32x2*>(qrow + 16 * EG4 + x2[r >> 1]);
+                        bq[slot][EG4] = v2[0];
+                        bq[slot][EG4 + 1] = v2[1];
+                    }
+                    if (E1) bq[slot][NET - 1] = qrow[16 * (EG4 + (E2 ? 2 : 0)) + x1[r >> 1]];
+                };
+                ldrow(0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r + 1 < 4) ldrow(r + 1, (r + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NFT; ++j) dV[j] = mfma16(pd[r], bo[r & 1][j], dV[j]);
+#pragma unroll
+                    for (int j = 0; j < NET; ++j) dK[j] = mfma16(ds[r], bq[r & 1][j], dK[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // ---- PAIR: the K-role wave owns P, the mask and dS; the V-role wave owns dP.  Exchange through LDS.
+            float* xch_pd = sm + P::oXch + (wave * 64 + lane) * 4;             // written by the K-role wave
+            float* xch_dp = sm + P::oXch + NW * 256 + (wave * 64 + lane) * 4;  // written by the V-role wave
+            float pr[4], dsc[4];
+            if (!role_v) {
+                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(ax + 4 * lq);
+                const f32x4 key4 = *reinterpret_cast<const f32x4*>(ax + 32 + 4 * lq);
+                f32x4 pdv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pr[r] = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
+                    dsc[r] = 1.f;
+                    if (a.thresh) dsc[r] = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
+                    pdv[r] = pr[r] * dsc[r];
+                }
+                *reinterpret_cast<f32x4*>(xch_pd) = pdv;
+            } else {
+                *reinterpret_cast<f32x4*>(xch_dp) = d0 + d1;
+            }
+            if (!(GZ_ABL & 64)) __syncthreads();  // both tiles of every pair are in LDS
             constexpr int FG4 = NFT / 4 * 4, EG4 = NET / 4 * 4;
             constexpr bool F2 = (NFT - FG4) >= 2, F1 = ((NFT - FG4) & 1) != 0;
             constexpr bool E2 = (NET - EG4) >= 2, E1 = ((NET - EG4) & 1) != 0;
-            // B fragments of k step r: one float per accumulator tile, read one k step ahead of its MFMAs
-            float bo[2][NFT], bq[2][NET];
-            auto ldrow = [&](int r, int slot) {
-                const float* orow = to + (4 * lq + r) * RSO;
-                const float* qrow = tq + (4 * lq + r) * RSQ;
+            float bb[2][NACC];  // B fragments of k step r, read one k step ahead of its MFMAs
+            if (!role_v) {
+                const f32x4 dp4 = *reinterpret_cast<const f32x4*>(xch_dp);
+                const f32x4 del4 = *reinterpret_cast<const f32x4*>(ax + 16 + 4 * lq);
+                float ds[4];
 #pragma unroll
-                for (int jg = 0; jg < NFT / 4; ++jg) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(orow + 64 * jg + x4[r >> 1]);
+                for (int r = 0; r < 4; ++r) ds[r] = pr[r] * (dp4[r] * dsc[r] - del4[r]);
+                {
+                    float* dw = dSs + cur * BWD_BL * RSD + (4 * lq) * RSD + (lr & 3) * KSD + 4 * wave + (lr >> 2);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bo[slot][4 * jg + e] = v4[e];
+                    for (int r = 0; r < 4; ++r) dw[r * RSD] = ds[r];
                 }
-                if (F2) {
-                    const f32x2 v2 = *reinterpret_cast<const f32x2*>(orow + 16 * FG4 + x2[r >> 1]);
-                    bo[slot][FG4] = v2[0];
-                    bo[slot][FG4 + 1] = v2[1];
+                auto ldq = [&](int r, int slot) {
+                    const float* qrow = tq + (4 * lq + r) * RSQ;
+#pragma unroll
+                    for (int jg = 0; jg < NET / 4; ++jg) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(qrow + 64 * jg + x4[r >> 1]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bb[slot][4 * jg + e] = v4[e];
+                    }
+                    if (E2) {
+                        const f32x2 v2 = *reinterpret_cast<const f32x2*>(qrow + 16 * EG4 + x2[r >> 1]);
+                        bb[slot][EG4] = v2[0];
+                        bb[slot][EG4 + 1] = v2[1];
+                    }
+                    if (E1) bb[slot][NET - 1] = qrow[16 * (EG4 + (E2 ? 2 : 0)) + x1[r >> 1]];
+                };
+                ldq(0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r + 1 < 4) ldq(r + 1, (r + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NET; ++j) acc[j] = mfma16(ds[r], bb[r & 1][j], acc[j]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (F1) bo[slot][NFT - 1] = orow[16 * (FG4 + (F2 ? 2 : 0)) + x1[r >> 1]];
+            } else {
+                const f32x4 pd4 = *reinterpret_cast<const f32x4*>(xch_pd);
+                auto ldo = [&](int r, int slot) {
+                    const float* orow = to + (4 * lq + r) * RSO;
 #pragma unroll
-                for (int jg = 0; jg < NET / 4; ++jg) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(qrow + 64 * jg + x4[r >> 1]);
+                    for (int jg = 0; jg < NFT / 4; ++jg) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(orow + 64 * jg + x4[r >> 1]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bq[slot][4 * jg + e] = v4[e];
+                        for (int e = 0; e < 4; ++e) bb[slot][4 * jg + e] = v4[e];
+                    }
+                    if (F2) {
+                        const f32x2 v2 = *reinterpret_cast<const f32x2*>(orow + 16 * FG4 + x2[r >> 1]);
+                        bb[slot][FG4] = v2[0];
+                        bb[slot][FG4 + 1] = v2[1];
+                    }
+                    if (F1) bb[slot][NFT - 1] = orow[16 * (FG4 + (F2 ? 2 : 0)) + x1[r >> 1]];
+                };
+                ldo(0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r + 1 < 4) ldo(r + 1, (r + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NFT; ++j) acc[j] = mfma16(pd4[r], bb[r & 1][j], acc[j]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (E2) {
-                    const f32x2 v2 = *reinterpret_cast<const f32x2*>(qrow + 16 * EG4 + x2[r >> 1]);
-                    bq[slot][EG4] = v2[0];
-                    bq[slot][EG4 + 1] = v2[1];
-                }
-                if (E1) bq[slot][NET - 1] = qrow[16 * (EG4 + (E2 ? 2 : 0)) + x1[r >> 1]];
-            };
-            ldrow(0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r + 1 < 4) ldrow(r + 1, (r + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < NFT; ++j) dV[j] = mfma16(pd[r], bo[r & 1][j], dV[j]);
-#pragma unroll
-                for (int j = 0; j < NET; ++j) dK[j] = mfma16(ds[r], bq[r & 1][j], dK[j]);
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // dQ of the PREVIOUS step (its dS tile was completed before the last barrier)
@@ -836,11 +985,17 @@ __global__ __launch_bounds__(NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) 
     }
     __syncthreads();
     if (GZ_ABL & 2) dK[0][0] += 0.f;
+    (void)dK, (void)dV, (void)acc;
     // epilogue: dK / dV tiles -> token rows through per-wave LDS staging, row-contiguous atomics
     if (!(GZ_ABL & 16)) {
-        float* st = sm + wave * 16 * P::STW;
-        flush_rows<NET, P::STW>(dK, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
-        flush_rows<NFT, P::STW>(dV, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
+        float* st = sm + wv * 16 * P::STW;
+        if constexpr (!PAIR) {
+            flush_rows<NET, P::STW>(dK, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
+            flush_rows<NFT, P::STW>(dV, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
+        } else {
+            if (!role_v) flush_rows<NET, P::STW>(acc, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
+            else flush_rows<NFT, P::STW>(acc, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
+        }
     }
 }
 
@@ -861,14 +1016,16 @@ static int launch_fwd(const AttnFwdArgs& a, hipStream_t st) {
 template <int ES, int NFT>
 static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     // 8 waves (128 tokens) per workgroup while the keys fit LDS beside the streamed tiles; 4 waves for E > 100
+    // (token groups of 16; with PAIR = wave pairs, the workgroup has 8 waves either way)
     constexpr int NW = (ES <= 25) ? 8 : 4;
-    using P = BwdLds<ES, NFT, NW>;
+    constexpr bool PAIR = ES > 25;
+    using P = BwdLds<ES, NFT, NW, PAIR>;
     static_assert(P::floats * 4 <= 160 * 1024, "backward LDS plan exceeds 160 KiB");
     const int nTT = cdiv(a.Tp, 16 * NW);
-    const dim3 grid(a.B * nTT * a.nsplit), block(NW * 64);
+    const dim3 grid(a.B * nTT * a.nsplit), block(P::NWV * 64);
     const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 && (((uintptr_t)a.Q | (uintptr_t)a.dO) & 15) == 0;
-    if (vec) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4>), grid, block, (size_t)P::floats * 4, st, a);
-    else hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1>), grid, block, (size_t)P::floats * 4, st, a);
+    if (vec) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4, PAIR>), grid, block, (size_t)P::floats * 4, st, a);
+    else hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1, PAIR>), grid, block, (size_t)P::floats * 4, st, a);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
