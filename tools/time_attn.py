@@ -23,7 +23,7 @@ def timed(fn, n=int(os.environ.get('N_IT', 5))):
 
 def main():
     ops = HipOps()
-    B, Tp, E, F, L = 16, 2491, int(os.environ.get('E', 100)), 200, 9000
+    B, Tp, E, F, L = int(os.environ.get('B', 16)), 2491, int(os.environ.get('E', 100)), 200, int(os.environ.get('L', 9000))
     g = torch.Generator(device='cuda').manual_seed(0)
     PX = torch.tanh(torch.randn(B, Tp, E, device='cuda', generator=g))
     X = torch.relu(torch.randn(B, Tp, F, device='cuda', generator=g))
