@@ -508,10 +508,24 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
     const float* Xb = a.X + (long long)b * a.Tp * a.F;
 
     // zero all of LDS once: pad words of the staged images must never hold NaN bit patterns
-    for (int i = tid; i < P::floats; i += NT) sm[i] = 0.f;
+    static_assert(P::floats % 4 == 0, "LDS plan is a whole number of 16-byte words");
+    for (int i = tid * 4; i < P::floats; i += NT * 4) *reinterpret_cast<f32x4*>(sm + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     // this workgroup's keys; batched straight-line loads from clamped addresses, columns past E stay zero
-    {
+    if constexpr (G == 4) {  // E % 4 == 0, 16-byte aligned rows: one vector per four columns (a swizzle chunk)
+        constexpr int KPT = (NW * 16 * (WQ / 4) + NT - 1) / NT;
+        f32x4 kk[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + NT * i, r = idx / (WQ / 4), c = 4 * (idx % (WQ / 4));
+            kk[i] = *reinterpret_cast<const f32x4*>(PXb + (long long)min(tt * 16 * NW + r, a.Tp - 1) * a.E + min(c, a.E - 4));
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + NT * i, r = idx / (WQ / 4), c = 4 * (idx % (WQ / 4));
+            if (r < NW * 16 && tt * 16 * NW + r < a.Tp && c < a.E) *reinterpret_cast<f32x4*>(Kp + img_off(r, c, RSQ)) = kk[i];
+        }
+    } else {
         constexpr int KPT = (NW * 16 * WQ + NT - 1) / NT;
         float kk[KPT];
 #pragma unroll
@@ -530,10 +544,21 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
     float vT[FS];
     if (do_v) {
         const float* vrow = Xb + (long long)min(tok, a.Tp - 1) * a.F;
+        if constexpr (G == 4) {  // F % 4 == 0: the four columns of a group are one aligned vector
 #pragma unroll
-        for (int s = 0; s < FS; ++s) {
-            const int f = 16 * (s >> 2) + 4 * lq + (s & 3);
-            vT[s] = vrow[min(f, a.F - 1)] * ((tok_ok && f < a.F) ? 1.f : 0.f);
+            for (int g4 = 0; g4 < FS / 4; ++g4) {
+                const int f = 16 * g4 + 4 * lq;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(vrow + min(f, a.F - 4));
+                const float keep = (tok_ok && f < a.F) ? 1.f : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vT[4 * g4 + e] = v[e] * keep;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < FS; ++s) {
+                const int f = 16 * (s >> 2) + 4 * lq + (s & 3);
+                vT[s] = vrow[min(f, a.F - 1)] * ((tok_ok && f < a.F) ? 1.f : 0.f);
+            }
         }
     }
 
@@ -1023,7 +1048,8 @@ static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     static_assert(P::floats * 4 <= 160 * 1024, "backward LDS plan exceeds 160 KiB");
     const int nTT = cdiv(a.Tp, 16 * NW);
     const dim3 grid(a.B * nTT * a.nsplit), block(P::NWV * 64);
-    const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 && (((uintptr_t)a.Q | (uintptr_t)a.dO) & 15) == 0;
+    const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 &&
+                     (((uintptr_t)a.Q | (uintptr_t)a.dO | (uintptr_t)a.PX | (uintptr_t)a.X) & 15) == 0;
     if (vec) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4, PAIR>), grid, block, (size_t)P::floats * 4, st, a);
     else hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1, PAIR>), grid, block, (size_t)P::floats * 4, st, a);
     GZSL_CHECK_LAUNCH();
