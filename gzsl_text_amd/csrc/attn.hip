@@ -111,12 +111,23 @@ __global__ __launch_bounds__(FWD_WAVES * 64, 2) void label_attn_fwd_kernel(AttnF
         const float* qrow = a.Q + (long long)min(lbl, a.L - 1) * a.E;
 #pragma unroll
         for (int s = 0; s < ES; ++s) {
+            if (G == 4 && s < 4 * NG) {  // E % 4 == 0: the four steps of a group are one aligned vector
+                if ((s & 3) == 0) {
+                    const int e = 16 * (s >> 2) + 4 * lq;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(qrow + min(e, a.E - 4));
+                    const float keep = (lbl_ok && e < a.E) ? 1.f : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qreg[s + j] = v[j] * keep;
+                }
+                continue;
+            }
             const int e = (s < 4 * NG) ? 16 * (s >> 2) + 4 * lq + (s & 3) : 16 * NG + 4 * (s - 4 * NG) + lq;
             qreg[s] = qrow[min(e, a.E - 1)] * ((lbl_ok && e < a.E) ? 1.f : 0.f);
         }
     }
     // zero both tiles once: pad columns are never written by the staging copy and must not hold NaN patterns
-    for (int i = tid; i < P::floats; i += NT) Ks[i] = 0.f;
+    static_assert(P::floats % 4 == 0, "LDS plan is a whole number of 16-byte words");
+    for (int i = tid * 4; i < P::floats; i += NT * 4) *reinterpret_cast<f32x4*>(Ks + i) = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // the 32-row tile of keys (values) is one contiguous block of 32*E (32*F) floats: copy it flat, G floats per
     // load, and re-stride into the padded LDS rows.  LDS offsets are loop-invariant: computed once.
@@ -1029,7 +1040,8 @@ static int launch_fwd(const AttnFwdArgs& a, hipStream_t st) {
     size_t smem = (size_t)FwdLds<ES, NFT>::floats * 4;
     const int nLT = cdiv(a.L, 16 * FWD_WAVES);
     const dim3 grid(a.B * nLT), block(FWD_WAVES * 64);
-    const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 && (((uintptr_t)a.PX | (uintptr_t)a.X) & 15) == 0;
+    const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 &&
+                     (((uintptr_t)a.PX | (uintptr_t)a.X | (uintptr_t)a.Q) & 15) == 0;
     if (vec && a.thresh) hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 4, true>), grid, block, smem, st, a);
     else if (vec) hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 4, false>), grid, block, smem, st, a);
     else if (a.thresh) hipLaunchKernelGGL((label_attn_fwd_kernel<ES, NFT, 1, true>), grid, block, smem, st, a);
