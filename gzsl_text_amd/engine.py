@@ -171,21 +171,32 @@ class BaseEngine:
         return O, lse, direct, logits
 
     def head_bwd(self, dlogits, O, lse, direct, X, PX, Q, clf, l_offset, L_total, seed, training, P, G,
-                 dX, dPX, dQ, need_encoder_grads=True):
-        """Returns dclf [L,D]; accumulates output_proj grads into G and (optionally) dX, dPX, dQ."""
+                 dX, dPX, dQ, need_encoder_grads=True, defer_wgrad=False):
+        """Returns dclf [L,D]; accumulates output_proj grads into G and (optionally) dX, dPX, dQ.
+
+        defer_wgrad=True returns (dclf, pending) instead and leaves the output_proj weight / bias gradients to
+        `head_wgrad(pending, G)`: they depend on nothing downstream, so the sharded path runs them while the
+        reduce-scatter of dX / dPX is on the wire."""
         ops = self.ops
         B, L, F_ = O.shape
         D = direct.shape[2]
         ddirect, dclf = ops.logits_bwd(direct, clf, dlogits, need_ddirect=need_encoder_grads)
         if not need_encoder_grads:
-            return dclf
+            return (dclf, None) if defer_wgrad else dclf
         dd2 = ddirect.view(B * L, D)
         O2 = O.view(B * L, F_)
-        ops.mm(dd2.t(), O2, out=G['output_proj.weight'], accumulate=True)
-        ops.colsum(dd2, out=G['output_proj.bias'])
+        if not defer_wgrad:
+            self.head_wgrad((dd2, O2), G)
         dO = ops.mm(dd2, P['output_proj.weight']).view(B, L, F_)
         ops.attn_bwd(dO, O, PX, X, Q, lse, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0, dPX, dX, dQ)
-        return dclf
+        return (dclf, (dd2, O2)) if defer_wgrad else dclf
+
+    def head_wgrad(self, pending, G):
+        if pending is None:
+            return
+        dd2, O2 = pending
+        self.ops.mm(dd2.t(), O2, out=G['output_proj.weight'], accumulate=True)
+        self.ops.colsum(dd2, out=G['output_proj.bias'])
 
 
 def zeros_like_params(P, names):

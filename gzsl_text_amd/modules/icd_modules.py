@@ -119,8 +119,13 @@ class _BaseModelFn(torch.autograd.Function):
         dPX = torch.zeros_like(PX)
         davg = torch.zeros(avg_shape, dtype=torch.float32, device=X.device)
         dgraph = torch.zeros(graph_shape, dtype=torch.float32, device=X.device)
-        dclf = eng.head_bwd(dlogits, O, lse, direct, X, PX, Q, clf, l0, L, seed, training, P, G, dX, dPX,
-                            davg[l0:l1])
+        pending = None
+        if bs is not None:
+            dclf, pending = eng.head_bwd(dlogits, O, lse, direct, X, PX, Q, clf, l0, L, seed, training, P, G, dX, dPX,
+                                         davg[l0:l1], defer_wgrad=True)
+        else:
+            dclf = eng.head_bwd(dlogits, O, lse, direct, X, PX, Q, clf, l0, L, seed, training, P, G, dX, dPX,
+                                davg[l0:l1])
         dgraph[l0:l1] = dclf
         if bs is not None:
             # the partial dX / dPX of this label shard are summed and scattered over the batch
@@ -130,6 +135,7 @@ class _BaseModelFn(torch.autograd.Function):
             beside = _Beside(dX)
             with beside:  # beside the reduce-scatters and the note encoder's backward
                 eng.label_bwd(davg, dgraph, lcache, P, gb, G)
+            eng.head_wgrad(pending, G)  # output_proj weight gradient: compute for the time the reduce-scatter is on the wire
             hx.wait()
             hp.wait()
             eng.encoder_bwd(dXl, dPXl, X[b0:b1], PX[b0:b1], e, x[b0:b1].contiguous(),
