@@ -162,7 +162,7 @@ class WganGpStep:
     as train_gan.py:223-308 orders them.  Parameters live in dicts of tensors (same keys as the reference's
     `generator` / `discriminator` / keyword-head state dicts); torch.optim.Adam does the updates."""
 
-    def __init__(self, ops, g, d, kw=None, lr=1e-4, critic_iters=5, reg_ratio=0.0, lam=10.0):
+    def __init__(self, ops, g, d, kw=None, lr=1e-4, critic_iters=5, reg_ratio=0.0, lam=10.0, capturable=False):
         self.eng = GanEngine(ops)
         self.g, self.d, self.kw = g, d, kw
         self.critic_iters, self.reg_ratio, self.lam = critic_iters, reg_ratio, lam
@@ -172,8 +172,12 @@ class WganGpStep:
         self._dp = {k: torch.nn.Parameter(v, requires_grad=False) for k, v in d.items()}
         self._kp = {} if kw is None else {k: torch.nn.Parameter(v, requires_grad=False)
                                           for k, v in kw.items() if k != 'word_emb'}
-        self.opt_d = torch.optim.Adam(list(self._dp.values()), lr=lr, betas=(0.5, 0.999))
-        self.opt_g = torch.optim.Adam(list(self._gp.values()) + list(self._kp.values()), lr=lr, betas=(0.5, 0.999))
+        # capturable=True keeps Adam's step counters on the device, so a whole step can be recorded into a HIP graph
+        # (`graphed_step` below): at the drivers' default batch of 8 the step is ~300 launches of microsecond kernels
+        extra = {'capturable': True} if capturable else {}
+        self.opt_d = torch.optim.Adam(list(self._dp.values()), lr=lr, betas=(0.5, 0.999), **extra)
+        self.opt_g = torch.optim.Adam(list(self._gp.values()) + list(self._kp.values()), lr=lr, betas=(0.5, 0.999),
+                                      **extra)
 
     def critic_step(self, real, lab, noise, alpha, sim=None):
         d_cost, gp, G, fake = self.eng.critic_iteration(self.d, self.g, real, lab, noise, alpha, sim, self.lam)
@@ -191,3 +195,27 @@ class WganGpStep:
             p.grad = Gk[k]
         self.opt_g.step()
         return g_cost, kw_loss, Gg, Gk, fake
+
+
+def graphed_step(fn, warmup=3):
+    """Record `fn()` (a full WGAN-GP step over STATIC input tensors, built with `capturable=True`) into one HIP graph
+    and return a replay callable.  Launch-bound at small batches (train_gan.py's default batch is 8): the eager step is
+    a few hundred kernel launches from Python, the replay is one graph launch.  The caller refreshes the static input
+    tensors in place between replays; the outputs of `fn` recorded at capture time are returned by every replay."""
+    if warmup < 1:  # state created lazily inside the recording (Adam's moments) would be re-zeroed by every replay
+        raise ValueError('graphed_step needs at least one eager warm-up step before the recording')
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up off the capture: lazy initialisation (optimizer state, workspaces)
+        for _ in range(warmup):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn()
+
+    def replay():
+        graph.replay()
+        return out
+    return replay
+

@@ -93,3 +93,52 @@ def test_label_gru_hip_matches_reference_golden():
         want = enc2.forward_enc(torch.from_numpy(idz), torch.from_numpy(mk), None, training=False, pool_mode='max')
     got = forward_enc_hip(enc2.to(DEV), torch.from_numpy(idz).to(DEV), torch.from_numpy(mk).to(DEV), 'max')
     close(got, want, 1e-4, 1e-5, 'HIP packed GRU vs torch GRU (E=200, 300 ragged descriptions)')
+
+
+def test_gan_step_replayed_as_hip_graph_matches_eager():
+    """The whole WGAN-GP step (critic iterations + generator iteration + Adam) records into one HIP graph: nothing in
+    the C ABI allocates or synchronises.  One eager step plus three replays must land on the parameters four eager steps reach."""
+    from gzsl_text_amd.gan_engine import WganGpStep, graphed_step
+    from gzsl_text_amd.ops_hip import HipOps
+    from tests.gan_checks import GAN_DIMS, _close_adam
+    from tests.golden import synth
+    kwargs = dict(GAN_DIMS['gan_step_medium'])
+    n_iters = kwargs.pop('n_iters')
+    s = synth.synth_gan(n_iters=n_iters, **kwargs)
+
+    def dev(d):
+        return {k: torch.from_numpy(v.copy()).to('cuda') for k, v in d.items()}
+
+    def t(a):
+        return torch.from_numpy(a).to('cuda')
+
+    its = [{k: t(v) for k, v in I.items()} for I in s['iters']]
+    kw_idx, kw_mask = t(s['kw_idx']), t(s['kw_mask'])
+    results = []
+    for graphed in (False, True):
+        step = WganGpStep(HipOps(), dev(s['g']), dev(s['d']), dev(s['kw']), lr=1e-4, critic_iters=n_iters, reg_ratio=0.01,
+                          capturable=True)
+        start = {k: v.clone() for k, v in list(step.g.items()) + list(step.d.items())}
+
+        def one():
+            for i in range(n_iters):
+                I = its[i]
+                step.critic_step(I['real'], I['lab'], I['noise'], I['alpha'], I['sim'])
+            I = its[n_iters]
+            return step.generator_step(I['lab'], I['noise'], I['sim'], kw_idx, kw_mask)[0]
+
+        if graphed:
+            one = graphed_step(one, warmup=1)   # 1 eager step (creates Adam's state) + 3 replays = 4 steps
+            for _ in range(3):
+                g_cost = one()
+        else:
+            for _ in range(4):
+                g_cost = one()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(g_cost))
+        results.append({k: v.detach().clone() for k, v in list(step.g.items()) + list(step.d.items())})
+        assert any(not torch.equal(results[-1][k], start[k]) for k in start)
+    for k in results[0]:
+        # same kernels, same order, same inputs; float atomics reorder sums, and Adam turns a rounding-noise gradient
+        # into a +-lr move per step (tests/gan_checks.py::_close_adam): bound = 4 steps, most elements tight
+        _close_adam(results[0][k].cpu().numpy(), results[1][k].cpu().numpy(), 4e-4, f'graph vs eager {k}')

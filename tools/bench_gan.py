@@ -15,7 +15,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gzsl_text_amd.gan_engine import WganGpStep  # noqa: E402
+from gzsl_text_amd.gan_engine import WganGpStep, graphed_step  # noqa: E402
 from gzsl_text_amd.ops_hip import HipOps  # noqa: E402
 from tests.golden import synth  # noqa: E402
 
@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reg-ratio', type=float, default=0.1)
+    ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (small batches are launch-bound)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     case = synth.synth_gan(seed=7, Bg=args.bg, D=400, Ls=400, ngh=800, ndh=800, E=200, Vk=4096, top_k=20, n_iters=5)
@@ -34,7 +35,7 @@ def main():
         return {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
 
     step = WganGpStep(HipOps(), dv(case['g']), dv(case['d']), dv(case['kw']), lr=1e-4, critic_iters=5,
-                      reg_ratio=args.reg_ratio)
+                      reg_ratio=args.reg_ratio, capturable=args.graph)
     its = [{k: torch.from_numpy(v).to(dev) for k, v in it.items()} for it in case['iters']]
     kw_idx, kw_mask = torch.from_numpy(case['kw_idx']).to(dev), torch.from_numpy(case['kw_mask']).to(dev)
 
@@ -45,6 +46,8 @@ def main():
         it = its[5]
         return step.generator_step(it['lab'], it['noise'], it['sim'], kw_idx, kw_mask)[0]
 
+    if args.graph:
+        one = graphed_step(one)
     for _ in range(args.warmup):
         one()
     torch.cuda.synchronize()
@@ -56,7 +59,7 @@ def main():
     assert bool(torch.isfinite(g_cost))
     flops = 7.8e7 * args.bg
     print(json.dumps({'metric': 'WGAN-GP samples/sec (5 critic + 1 generator iteration, Adam)', 'value': args.bg / dt,
-                      'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'Bg': args.bg, 'reg_ratio': args.reg_ratio,
+                      'unit': 'samples/s', 'ms_per_step': dt * 1e3, 'Bg': args.bg, 'reg_ratio': args.reg_ratio, 'hip_graph': bool(args.graph),
                       'algorithmic_tflops': flops / dt / 1e12, 'frac_of_157.3': flops / dt / 1e12 / 157.3,
                       'dtype': 'f32', 'data': 'synthetic'}))
 
