@@ -100,7 +100,7 @@ def test_gan_step_replayed_as_hip_graph_matches_eager():
     the C ABI allocates or synchronises.  One eager step plus three replays must land on the parameters four eager steps reach."""
     from gzsl_text_amd.gan_engine import WganGpStep, graphed_step
     from gzsl_text_amd.ops_hip import HipOps
-    from tests.gan_checks import GAN_DIMS, _close_adam
+    from tests.gan_checks import GAN_DIMS
     from tests.golden import synth
     kwargs = dict(GAN_DIMS['gan_step_medium'])
     n_iters = kwargs.pop('n_iters')
@@ -141,4 +141,6 @@ def test_gan_step_replayed_as_hip_graph_matches_eager():
     for k in results[0]:
         # same kernels, same order, same inputs; float atomics reorder sums, and Adam turns a rounding-noise gradient
         # into a +-lr move per step (tests/gan_checks.py::_close_adam): bound = 4 steps, most elements tight
-        _close_adam(results[0][k].cpu().numpy(), results[1][k].cpu().numpy(), 4e-4, f'graph vs eager {k}')
+        a, b = results[0][k].double(), results[1][k].double()
+        assert float((a - b).abs().max()) <= 2.02 * 4e-4 + 1e-6, k
+        assert float((a - b).abs().mean()) <= 1e-4, k
