@@ -263,9 +263,14 @@ def capture_label_rnn():
 
 if __name__ == '__main__':
     torch.manual_seed(0)
+    only = sys.argv[1:]   # `make_golden.py base_gate_e200` captures just the named base cases
     for name, kw in synth.BASE_CASES.items():
+        if only and name not in only:
+            continue
         capture_base(name, kw, train=False)
         capture_base(name, kw, train=True)
+    if only:
+        sys.exit(0)
     capture_gan_model()
     capture_gan_step('gan_step_tiny', seed=11, n_iters=2, store_inputs=True,
                      Bg=6, D=16, Ls=16, ngh=24, ndh=20, E=8, Vk=30, top_k=5)

@@ -126,5 +126,7 @@ BASE_CASES = {
     'base_conv_tiny': dict(seed=1, B=2, T=33, E=8, H=12, L=9, N=14, Td=5, V=40, F=20, encoder='conv'),
     'base_gate_medium': dict(seed=2, B=2, T=300, E=100, H=100, L=256, N=300, Td=12, V=500, F=200,
                              labels_per_note=8),
+    # E = H = 200 (what the drivers build from the shipped resources): the E > 100 kernel variants, 3 token tiles of 64
+    'base_gate_e200': dict(seed=3, B=2, T=150, E=200, H=200, L=70, N=90, Td=8, V=120, F=64, labels_per_note=5),
 }
 DROP_SEED = 1234
