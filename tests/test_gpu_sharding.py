@@ -43,7 +43,7 @@ def _worker(rank, world, port, name, train, q, backend='gloo'):
 
 
 @pytest.mark.parametrize('name,world,train', [('base_gate_medium', 2, True), ('base_gate_tiny', 3, True),
-                                              ('base_gate_tiny', 2, False)])
+                                              ('base_gate_tiny', 2, False), ('base_gate_e200', 2, True)])
 def test_hip_label_sharding_matches_unsharded_golden(name, world, train):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
