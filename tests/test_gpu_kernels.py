@@ -402,3 +402,60 @@ def test_ldam_bce_many_blocks(ops, ref):
     lossr, dlr, _ = ref.ldam_bce(logits, y, margin, 2.0, 1.0 / B)
     close(loss, lossr, 2e-6, 1e-3, 'ldam bce loss over 563 blocks')
     close(dl, dlr, 1e-5, 1e-7, 'dlogits')
+
+
+def test_attention_full_size_properties(ops):
+    """BASELINE.json configs[1] sizes (B=16, T'=2491, E=100, F=200, L=9000), where the oracle is too slow: properties
+    that do not depend on size.  (1) P is a distribution: with all-ones values and no dropout every output is 1.
+    (2) label shards reproduce the unsharded rows.  (3) the backward is linear in dO.  (4) sum_t dS[l,t] = 0 for
+    every label, so with the same key at every token the query gradient vanishes."""
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    B, Tp, E, F, L = 16, 2491, 100, 200, 9000
+    PX = torch.tanh(torch.randn(B, Tp, E, device=DEV, generator=gen))
+    X = torch.relu(torch.randn(B, Tp, F, device=DEV, generator=gen))
+    Q = torch.randn(L, E, device=DEV, generator=gen) * 0.2
+    # (1)
+    O1, lse1 = ops.attn_fwd(PX, torch.ones_like(X), Q, 0, L, 7, 0.0)
+    assert float((O1 - 1).abs().max()) < 2e-5
+    # logsumexp bounds: max_t s <= lse <= max_t s + log T'
+    smax = torch.stack([(PX[b] @ Q[:512].t()).max(0).values for b in range(B)])
+    assert bool((lse1[:, :512] >= smax - 1e-4).all()) and bool((lse1[:, :512] <= smax + np.log(Tp) + 1e-4).all())
+    # (2)
+    O, lse = ops.attn_fwd(PX, X, Q, 0, L, 7, 0.2)
+    for l0, l1 in ((0, 1125), (4500, 9000), (8999, 9000)):
+        Os, lses = ops.attn_fwd(PX, X, Q[l0:l1].contiguous(), l0, L, 7, 0.2)
+        close(Os, O[:, l0:l1], 1e-5, 2e-6, f'full-size shard [{l0},{l1})')
+        close(lses, lse[:, l0:l1], 1e-6, 2e-6, f'full-size shard lse [{l0},{l1})')
+    # (3)
+    dO = torch.randn(B, L, F, device=DEV, generator=gen) * 0.01
+    outs = []
+    for scale in (1.0, -2.0):
+        dPX, dX, dQ = torch.zeros_like(PX), torch.zeros_like(X), torch.zeros_like(Q)
+        ops.attn_bwd((dO * scale).contiguous(), O, PX, X, Q, lse, 0, L, 7, 0.2, dPX, dX, dQ)
+        outs.append((dPX, dX, dQ))
+    for a, b, what in zip(outs[0], outs[1], ('dPX', 'dX', 'dQ')):
+        assert bool(torch.isfinite(a).all())
+        close(b, -2.0 * a, 2e-4, 2e-5 * float(a.abs().max()), f'linearity of {what} in dO')
+    # (4) identical keys at every token: S[l,t] does not depend on t, P is uniform, dS[l,t] = P (dP[l,t] - delta[l])
+    # sums to zero over t, so dQ = sum_t dS[l,t] K[t] = K * 0 = 0 (up to rounding against the size of its terms)
+    PXc = PX[:, :1].expand(B, Tp, E).contiguous()
+    Oc, lsec = ops.attn_fwd(PXc, X, Q, 0, L, 7, 0.0)
+    dPX, dX, dQ = torch.zeros_like(PX), torch.zeros_like(X), torch.zeros_like(Q)
+    ops.attn_bwd(dO, Oc, PXc, X, Q, lsec, 0, L, 7, 0.0, dPX, dX, dQ)
+    terms = float(dO.abs().mean()) * float(X.abs().mean()) * F   # size of one dP term
+    assert float(dQ.abs().max()) < 1e-4 * terms * B, (float(dQ.abs().max()), terms)
+
+
+def test_conv_full_size_linearity(ops):
+    """Implicit-GEMM conv at cfg2 size: conv(e1 + e2) - b = (conv(e1) - b) + (conv(e2) - b) before the ReLU is not
+    observable, so use non-negative inputs and weights (ReLU inactive) and check additivity and the bias shift."""
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    B, T, E, F, k = 16, 2500, 100, 200, 10
+    e1, e2 = torch.rand(B, T, E, device=DEV, generator=gen), torch.rand(B, T, E, device=DEV, generator=gen)
+    W, b = torch.rand(F, E, k, device=DEV, generator=gen) * 0.01, torch.rand(F, device=DEV, generator=gen)
+    y1, y2, y12 = ops.conv_relu(e1, W, b), ops.conv_relu(e2, W, b), ops.conv_relu(e1 + e2, W, b)
+    assert y1.shape == (B, T - k + 1, F)
+    close(y12 + b, y1 + y2, 1e-5, 1e-4, 'conv additivity (ReLU inactive)')
+    # one output against a direct dot product
+    want = float((e1[3, 77:77 + k].t() * W[5]).sum() + b[5])
+    assert abs(float(y1[3, 77, 5]) - want) < 1e-4 * abs(want)
