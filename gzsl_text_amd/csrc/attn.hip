@@ -448,6 +448,7 @@ __device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NARR], float* st
                 for (int r = 0; r < 4; ++r) st[(4 * lq + r) * STW + c] = tiles[j][r];
             }
         }
+        wave_lds_fence();  // the rows read below were staged by other lanes of this wave
         const int ncol = min(128, 16 * NTILES - 128 * ps);
         for (int trow = 0; trow < 16; ++trow) {
             const int t = tok0 + trow;
@@ -457,6 +458,7 @@ __device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NARR], float* st
                 if (col < width) atomicAdd(out + (long long)t * ld + col, st[trow * STW + c]);
             }
         }
+        wave_lds_fence();  // ... and the next pass overwrites them
     }
 }
 

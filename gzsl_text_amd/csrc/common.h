@@ -23,6 +23,15 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Orders LDS traffic between the lanes of ONE wave: stores issued before it are visible to loads issued after it.  LDS
+// operations of a wave retire in order, so this emits no instruction; it only forbids the compiler to move the loads
+// above the stores (nothing else in the source does).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

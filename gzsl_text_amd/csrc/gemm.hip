@@ -362,6 +362,7 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
                     for (int r = 0; r < 4; ++r) st[(4 * lq + r) * STW + c] = acc[0][j][r];
                 }
             }
+            wave_lds_fence();  // the rows read below were staged by other lanes of this wave
             const int col = n0 + 128 * ps + c4;
             const bool col_ok = (128 * ps + c4 < 16 * WTN) && col < g.N;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
                 }
                 *reinterpret_cast<f32x4*>(cp) = v;
             }
+            wave_lds_fence();  // ... and the next pass overwrites them
         }
         return;
     }

@@ -98,15 +98,32 @@ def exported_names():
     return sorted(_PROTOS) + ['gzsl_build_info']
 
 
-def ptr(t):
-    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+def _current_device():
+    return torch.cuda.current_device()
+
+
+def dptr(t):
+    """Device pointer of a HIP tensor or strided view (None -> NULL).
+
+    Launches go to the CURRENT device's current stream (`stream()`), so a tensor that lives on another device would be
+    dereferenced by the wrong GPU: raise instead (a model moved with `.to('cuda:1')` needs `torch.cuda.set_device(1)`
+    or a `with torch.cuda.device(1):` block around its calls, as one-process-per-GPU launchers do)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError('gzsl_text_amd kernels need tensors on a HIP device (got a CPU tensor); there is no CPU path')
-    if not t.is_contiguous():
-        raise RuntimeError('gzsl_text_amd kernels need contiguous tensors')
+    cur = _current_device()
+    if t.device.index != cur:
+        raise RuntimeError(f'tensor lives on cuda:{t.device.index} but the current device is cuda:{cur}: kernels launch '
+                           f'on the current device\'s stream (call torch.cuda.set_device({t.device.index}) first)')
     return t.data_ptr()
+
+
+def ptr(t):
+    """Device pointer of a contiguous HIP tensor on the current device (None -> NULL)."""
+    if t is not None and t.is_cuda and not t.is_contiguous():
+        raise RuntimeError('gzsl_text_amd kernels need contiguous tensors')
+    return dptr(t)
 
 
 def stream():

@@ -351,6 +351,8 @@ class _GanModelFn(torch.autograd.Function):
         clf = clf[:L].contiguous()
         if margin is not None:
             margin = margin[:L].contiguous()
+        # y is NOT cut to eval_code_size: the reference (icd_modules.py:275) raises a shape error for targets wider than
+        # the logits, and so does HipOps.ldam_bce
         B = x.shape[0]
         mask_c = None if mask is None else mask.contiguous().to(torch.float32)
         X, PX, _ = eng.encoder_fwd(P, x.contiguous(), mask_c, seed, training)

@@ -8,7 +8,7 @@ back to torch arithmetic: torch supplies device memory (empty/zeros), views and 
 import torch
 
 from . import hip
-from .hip import ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, GzslGemm, call, ptr  # noqa: F401
+from .hip import ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU, GzslGemm, call, dptr, ptr  # noqa: F401
 
 INT_MAX = 2 ** 31 - 1
 
@@ -54,15 +54,15 @@ class HipOps:
                 # applies the unpack / accumulate / epilogue exactly as for a real split
                 split, kper = 2, max(32, (K + 31) // 32 * 32)
             slab = torch.empty((split, M, N), dtype=torch.float32, device=out.device)
-            g.C, g.ldc, g.bias, g.act, g.accumulate = slab.data_ptr(), N, None, ACT_NONE, 0
+            g.C, g.ldc, g.bias, g.act, g.accumulate = dptr(slab), N, None, ACT_NONE, 0
             g.split_k, g.k_per_split, g.slab_stride = split, kper, M * N
             call('gzsl_gemm', g)
             uk, ue = unpack if unpack is not None else (0, 0)
             ldo = out.stride(0) if (unpack is None and out.dim() == 2) else N
-            call('gzsl_splitk_reduce', slab.data_ptr(), M * N, split, out.data_ptr(), M, N, ldo,
+            call('gzsl_splitk_reduce', dptr(slab), M * N, split, dptr(out), M, N, ldo,
                  ptr(bias), act, int(accumulate), uk, ue)
         else:
-            g.C, g.ldc = out.data_ptr(), out.stride(0)
+            g.C, g.ldc = dptr(out), out.stride(0)
             g.bias, g.act, g.accumulate = ptr(bias), act, int(accumulate)
             g.split_k, g.k_per_split, g.slab_stride = 1, 0, 0
             call('gzsl_gemm', g)
@@ -81,7 +81,7 @@ class HipOps:
         if not A.is_cuda:
             raise RuntimeError('gzsl_text_amd kernels need tensors on a HIP device; there is no CPU path')
         g = GzslGemm()
-        g.A, g.B = A.data_ptr(), B.data_ptr()
+        g.A, g.B = dptr(A), dptr(B)
         g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span = max(M, 1), 0, A.stride(0), A.stride(1), 0, INT_MAX
         g.k_inner, g.a_kbs, g.b_kbs = max(K, 1), 0, 0
         g.b_sk, g.b_sn = B.stride(0), B.stride(1)
@@ -100,9 +100,9 @@ class HipOps:
             out = torch.zeros(N, dtype=torch.float32, device=x2d.device)
         if M >= 4096:  # partial sums through a workspace instead of thousands of same-address atomics
             work = torch.empty(min(512, (M + 127) // 128) * N, dtype=torch.float32, device=x2d.device)
-            call('gzsl_colsum_ws', x2d.data_ptr(), ptr(out), M, N, x2d.stride(0), ptr(work), work.numel())
+            call('gzsl_colsum_ws', dptr(x2d), ptr(out), M, N, x2d.stride(0), ptr(work), work.numel())
         else:
-            call('gzsl_colsum', x2d.data_ptr(), ptr(out), M, N, x2d.stride(0))
+            call('gzsl_colsum', dptr(x2d), ptr(out), M, N, x2d.stride(0))
         return out
 
     def act_bwd_(self, d, y, act):
@@ -135,7 +135,7 @@ class HipOps:
         call('gzsl_conv_weight_pack', ptr(Wc), ptr(Wp), None, F_, E, k)
         X = torch.empty((B, Tp, F_), dtype=torch.float32, device=e.device)
         g = GzslGemm()
-        g.A, g.B = e.data_ptr(), Wp.data_ptr()
+        g.A, g.B = dptr(e), dptr(Wp)
         g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span = Tp, T * E, E, 1, 0, INT_MAX
         g.k_inner, g.a_kbs, g.b_kbs = k * E, 0, 0
         g.b_sk, g.b_sn = 1, k * E
@@ -154,7 +154,7 @@ class HipOps:
         # weight gradient, computed transposed ([k*E, F]) so that N = F uses the 208-wide tile
         dWc = torch.empty((F_, E, k), dtype=torch.float32, device=dev)
         g = GzslGemm()
-        g.A, g.B = e.data_ptr(), dY.data_ptr()
+        g.A, g.B = dptr(e), dptr(dY)
         M, N, K = k * E, F_, B * Tp
         g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span = M, 0, 1, E, 0, INT_MAX
         g.k_inner, g.a_kbs = Tp, T * E
@@ -164,7 +164,7 @@ class HipOps:
             dWc.zero_()
             for b in range(B):
                 g2 = GzslGemm()
-                g2.A, g2.B = e[b].data_ptr(), dY[b].data_ptr()
+                g2.A, g2.B = dptr(e[b]), dptr(dY[b])
                 g2.a_mb, g2.a_mbs, g2.a_sm, g2.a_sk, g2.a_shift, g2.a_span = M, 0, 1, E, 0, INT_MAX
                 g2.k_inner, g2.a_kbs, g2.b_sk, g2.b_sn, g2.b_kbs, g2.alpha = Tp, 0, F_, 1, 0, 1.0
                 self._launch(g2, M, N, Tp, dWc, None, ACT_NONE, True, 1, 0, unpack=(k, E))
@@ -177,7 +177,7 @@ class HipOps:
             call('gzsl_conv_weight_pack', ptr(Wc), None, ptr(Wflip), F_, E, k)
             de = torch.empty((B, T, E), dtype=torch.float32, device=dev)
             g = GzslGemm()
-            g.A, g.B = dY.data_ptr(), Wflip.data_ptr()
+            g.A, g.B = dptr(dY), dptr(Wflip)
             g.a_mb, g.a_mbs, g.a_sm, g.a_sk = T, Tp * F_, F_, 1
             g.a_shift, g.a_span = -(k - 1) * F_, Tp * F_
             g.k_inner, g.a_kbs, g.b_kbs = k * F_, 0, 0
@@ -222,7 +222,7 @@ class HipOps:
     def gru_seq_step_(self, gi_all, t, gh, h, mask, pool, pool_mode):
         """Step t of the packed label GRU (inference): gi_all [Bg,T,3H], gh [Bg,3H]; updates h (and pool) in place."""
         Bg, T, H3 = gi_all.shape
-        call('gzsl_gru_seq_step', gi_all[:, t].data_ptr(), T * H3, ptr(gh), ptr(h), ptr(mask), T, t, ptr(pool),
+        call('gzsl_gru_seq_step', dptr(gi_all[:, t]), T * H3, ptr(gh), ptr(h), ptr(mask), T, t, ptr(pool),
              {None: 0, 'last': 0, 'max': 1, 'mean': 2}[pool_mode], Bg, H3 // 3)
 
     # ------------------------------------------------------------------------------------ attention + head + loss
@@ -274,6 +274,12 @@ class HipOps:
 
     def ldam_bce(self, logits, y, margin, C, inv_b, need_grad=True, need_probs=False):
         B, L = logits.shape
+        # the kernel reads y with the logits' row pitch and margin[l] for l < L: a wider y (or label_indices beyond
+        # eval_code_size) would silently pair targets with the wrong columns where the reference raises a shape error
+        if tuple(y.shape) != (B, L):
+            raise RuntimeError(f'ldam_bce: targets {tuple(y.shape)} do not match logits {(B, L)}')
+        if margin is not None and margin.numel() != L:
+            raise RuntimeError(f'ldam_bce: {margin.numel()} margins for {L} labels')
         loss = torch.zeros((), dtype=torch.float32, device=logits.device)
         dlogits = torch.empty_like(logits) if need_grad else None
         probs = torch.empty_like(logits) if need_probs else None
@@ -301,8 +307,8 @@ class HipOps:
             assert probs.shape == (B, Lc) and probs.stride(1) == 1 and probs.dtype == torch.float32
         if not logits.is_cuda:
             raise RuntimeError('gzsl_text_amd kernels need tensors on a HIP device; there is no CPU path')
-        call('gzsl_eval_counts', logits.data_ptr(), logits.stride(0), y.data_ptr(), y.stride(0), ptr(counts),
-             None if probs is None else probs.data_ptr(), 0 if probs is None else probs.stride(0), B, Lc)
+        call('gzsl_eval_counts', dptr(logits), logits.stride(0), dptr(y), y.stride(0), ptr(counts),
+             None if probs is None else dptr(probs), 0 if probs is None else probs.stride(0), B, Lc)
         return counts
 
     def forward_final(self, fc, feats, labels, margin, C, scale, need_grad=True):

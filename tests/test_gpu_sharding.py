@@ -9,12 +9,15 @@ import traceback
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
-from tests.test_sharding_cpu import _free_port
+from tests.test_sharding_cpu import run_ranks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
+
+
+def _worker_nccl(rank, world, port, name, train, q):
+    _worker(rank, world, port, name, train, q, backend='nccl')
 
 
 def _worker(rank, world, port, name, train, q, backend='gloo'):
@@ -45,17 +48,7 @@ def _worker(rank, world, port, name, train, q, backend='gloo'):
 @pytest.mark.parametrize('name,world,train', [('base_gate_medium', 2, True), ('base_gate_tiny', 3, True),
                                               ('base_gate_tiny', 2, False), ('base_gate_e200', 2, True)])
 def test_hip_label_sharding_matches_unsharded_golden(name, world, train):
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, train, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=200) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in res:
-        assert msg == 'ok', f'rank {rank}:\n{msg}'
+    run_ranks(_worker, world, (name, train), timeout=200)
 
 
 @pytest.mark.parametrize('train', [True, False])
@@ -64,10 +57,4 @@ def test_rccl_backend_single_rank(train):
     and reduce-scatters started with async_op=True and waited on, second-stream label encoder beside them), on the one
     GPU a test box has: a process group of ONE rank.  Catches misuse of the RCCL API (layouts, dtypes, handles, stream
     ordering); the multi-rank arithmetic is pinned by the gloo tests above."""
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), 'base_gate_medium', train, q, 'nccl'))
-    p.start()
-    rank, msg = q.get(timeout=200)
-    p.join(timeout=60)
-    assert msg == 'ok', msg
+    run_ranks(_worker_nccl, 1, ('base_gate_medium', train), timeout=200)

@@ -89,3 +89,27 @@ def test_gan_variant_matches_reference():
         helpers.close(model.output_fc.weight.grad, g[f'ff_dfc{step}'], 1e-4, 1e-6, f'forward_final grad {step}')
         opt.step()
         helpers.close(model.output_fc.weight, g[f'ff_fc_after{step}'], 1e-5, 1e-6, f'AdamW params after {step}')
+
+
+def test_pointer_helper_rejects_tensor_on_another_device(monkeypatch):
+    """launches go to the CURRENT device's stream, so a tensor living on another device must raise instead
+    of being dereferenced by the wrong GPU.  No GPU here: stand-in tensor objects + a patched current device."""
+    from types import SimpleNamespace
+    from gzsl_text_amd import hip
+
+    def fake(index, contiguous=True):
+        return SimpleNamespace(is_cuda=True, device=SimpleNamespace(index=index), is_contiguous=lambda: contiguous,
+                               data_ptr=lambda: 0x1000 + index)
+
+    monkeypatch.setattr(hip, '_current_device', lambda: 0)
+    assert hip.ptr(fake(0)) == 0x1000 and hip.dptr(fake(0, contiguous=False)) == 0x1000 and hip.ptr(None) is None
+    with pytest.raises(RuntimeError, match='current device'):
+        hip.ptr(fake(1))
+    with pytest.raises(RuntimeError, match='current device'):
+        hip.dptr(fake(1, contiguous=False))
+    with pytest.raises(RuntimeError, match='contiguous'):
+        hip.ptr(fake(0, contiguous=False))
+    monkeypatch.setattr(hip, '_current_device', lambda: 1)
+    assert hip.ptr(fake(1)) == 0x1001
+    with pytest.raises(RuntimeError, match='CPU tensor'):
+        hip.ptr(torch.zeros(3))

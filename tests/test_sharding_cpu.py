@@ -47,18 +47,45 @@ def _worker(rank, world, port, name, train, q):
         q.put((rank, traceback.format_exc()))
 
 
-def _run(world, name, train):
+def run_ranks(target, world, args, timeout=240):
+    """Spawn `world` rank processes running target(rank, world, port, *args, q); every rank must post 'ok' and exit 0.
+    Whatever happens (a rank that dies without posting, a timeout, a failed assert) no process is left behind: live
+    ranks would otherwise sit in a collective and keep their memory for the rest of the session."""
+    import queue
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, train, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=240) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    for rank, msg in res:
-        assert msg == 'ok', f'rank {rank}:\n{msg}'
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    res = []
+    try:
+        for p in procs:
+            p.start()
+        for _ in procs:
+            try:
+                res.append(q.get(timeout=timeout))
+            except queue.Empty:
+                codes = [p.exitcode for p in procs]
+                raise AssertionError(f'only {len(res)} of {world} ranks reported within {timeout} s; exit codes {codes}; '
+                                     f'reports so far: {res}')
+            if res[-1][1] != 'ok':  # a failed rank leaves its peers blocked in a collective: stop waiting for them
+                break
+        for rank, msg in res:
+            assert msg == 'ok', f'rank {rank}:\n{msg}'
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0, f'rank process exit code {p.exitcode}'
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
+
+
+def _run(world, name, train):
+    run_ranks(_worker, world, (name, train))
 
 
 @pytest.mark.parametrize('train', [False, True])
