@@ -67,6 +67,14 @@ def test_wgan_gp_step_matches_reference_golden(name):
     run_gan_step_check(name, HipOps(), DEV)
 
 
+def test_gan_module_api_on_hip_follows_train_gan_call_order():
+    """The nn.Module mirrors train_gan.py:243-306 calls (generator, critic, gradient penalty, keyword head) on cuda:0
+    with HIP kernels underneath and torch autograd around them, against the reference's golden vectors."""
+    from gzsl_text_amd.ops_hip import HipOps
+    from tests.gan_checks import run_gan_module_api_check
+    run_gan_module_api_check(HipOps(), DEV)
+
+
 def test_label_gru_hip_matches_reference_golden():
     """Packed label GRU (lm_module.py:68-88, training=False) on the HIP kernels and the cache filled through it."""
     from gzsl_text_amd.modules.lm_module import LabelEncodingCache, RNNLabelEncoder, forward_enc_hip
