@@ -20,6 +20,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 // Returned for argument errors (shape the kernels were not instantiated for, bad sizes).
 #define GZSL_EINVAL 1001
+// (GZSL_ETOOBIG 1002: include/gzsl_hip.h)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -2,6 +2,7 @@
 // CSR neighbour mean, GRU gate math, classifier head, LDAM + BCE, AdamW, and the small backward helpers.
 // Each kernel is a grid-stride loop with lanes along the contiguous (feature) dimension, so every wave touches
 // 256 consecutive bytes per instruction; reductions go wave-shuffle -> one float atomic per wave/row.
+#include <mutex>
 #include "common.h"
 #include "rng.h"
 #include "../../include/gzsl_hip.h"
@@ -709,6 +710,44 @@ extern "C" int gzsl_colsum(const float* x, float* out, long long M, int N, int l
 extern "C" int gzsl_colsum_ws(const float* x, float* out, long long M, int N, int ld, float* work, long long work_floats,
                               void* stream) {
     return colsum_launch(x, out, M, N, ld, work, work_floats, ST);
+}
+
+// ---- allocation-free column sum (no counterpart in the reference; see include/gzsl_hip.h) ---------------------------
+// The partial sums of gzsl_colsum_ws live in a file-scope device array instead of a caller workspace.  Each GPU the
+// library runs on holds its own copy at its own address until the process ends; in host code the array's NAME is only a
+// stand-in for hipGetSymbolAddress (handing it to a kernel would fault), so the address is looked up once per device
+// and kept.
+#define GZ_SCRATCH_FLOATS (GZSL_COLSUM_STATIC_MAX_N * 64)  // 2 MiB: >= 64 row blocks of partial sums at the widest N
+static __device__ __align__(256) float gz_colsum_scratch[GZ_SCRATCH_FLOATS];
+#define GZ_MAX_DEVICES 64
+static float* g_scratch_ptr[GZ_MAX_DEVICES];  // per device; written once under g_scratch_mu
+static std::mutex g_scratch_mu;
+
+static int scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= GZ_MAX_DEVICES) return GZSL_EINVAL;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(gz_colsum_scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return GZSL_EINVAL;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int gzsl_colsum_static(const float* x, float* out, long long M, int N, int ld, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (N > GZSL_COLSUM_STATIC_MAX_N) return GZSL_ETOOBIG;
+    float* work = nullptr;
+    const int rc = scratch_for_current_device(&work);
+    if (rc != 0) return rc;
+    // every partial-sum word the finish kernel reads is written by this call's first kernel: nothing to clear
+    return colsum_launch(x, out, M, N, ld, work, GZ_SCRATCH_FLOATS, ST);
 }
 
 extern "C" int gzsl_multihot(const int64_t* y_indices, int W, float* y, int B, int L, void* stream) {

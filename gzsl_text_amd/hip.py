@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('GZSL_HIP_LIB') or os.path.join(_HERE, 'lib', 'libgzsl
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_LRELU = 0, 1, 2, 3
 EINVAL = 1001
+ETOOBIG = 1002
 
 c_void_p, c_int, c_ll, c_float, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_uint32
 
@@ -54,6 +55,7 @@ _PROTOS = {
     'gzsl_act_bwd': [c_void_p, c_void_p, c_ll, c_int, c_void_p],
     'gzsl_colsum': [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p],
     'gzsl_colsum_ws': [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p, c_ll, c_void_p],
+    'gzsl_colsum_static': [c_void_p, c_void_p, c_ll, c_int, c_int, c_void_p],
     'gzsl_multihot': [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p],
     'gzsl_eval_counts': [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'gzsl_conv_weight_pack': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
@@ -134,6 +136,8 @@ def check(rc, what):
     if rc != 0:
         if rc == EINVAL:
             raise RuntimeError(f'{what}: unsupported arguments (GZSL_EINVAL)')
+        if rc == ETOOBIG:
+            raise RuntimeError(f'{what}: size beyond the entry point\'s stated maximum (GZSL_ETOOBIG, include/gzsl_hip.h)')
         raise RuntimeError(f'{what}: HIP error {rc}')
 
 

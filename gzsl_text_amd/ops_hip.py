@@ -105,6 +105,13 @@ class HipOps:
             call('gzsl_colsum', dptr(x2d), ptr(out), M, N, x2d.stride(0))
         return out
 
+    def colsum_static_(self, x2d, out):
+        """out[n] += sum_m x2d[m,n] through gzsl_colsum_static: no workspace tensor, nothing allocated (N <= 8192)."""
+        M, N = x2d.shape
+        assert x2d.stride(1) == 1 and out.numel() == N
+        call('gzsl_colsum_static', dptr(x2d), ptr(out), M, N, x2d.stride(0))
+        return out
+
     def act_bwd_(self, d, y, act):
         call('gzsl_act_bwd', ptr(d), ptr(y), d.numel(), act)
         return d

@@ -4,7 +4,8 @@
  * ATen/cuDNN/cuBLAS.  Each entry point below names the reference statement(s) it replaces (path:line under the
  * reference tree).  All pointers are DEVICE pointers to contiguous row-major buffers (fp32 unless said otherwise,
  * token / label ids int64 as the reference's LongTensors); `stream` is a hipStream_t; nothing allocates or syncs.
- * Return value: 0 on success, a hipError_t (>0) from the launch, or GZSL_EINVAL (1001) for unsupported arguments.
+ * Return value: 0 on success, a hipError_t (>0) from the launch, GZSL_EINVAL (1001) for unsupported arguments, or
+ * GZSL_ETOOBIG (1002) where an entry point states a size limit.
  * The host side (gzsl_text_amd/, Python, mirroring the modules package) binds these with ctypes; see INTEGRATION.md.
  */
 #ifndef GZSL_HIP_H
@@ -129,6 +130,16 @@ int gzsl_colsum(const float* x, float* out, long long M, int N, int ld, void* st
  * second launch adds them to out in a fixed order, instead of up to 4096 same-address atomics per column. */
 int gzsl_colsum_ws(const float* x, float* out, long long M, int N, int ld, float* work, long long work_floats,
                    void* stream); /* out[n] += sum_m x[m*ld+n] */
+/* Allocation-free variant of gzsl_colsum_ws.  No counterpart in the reference: it is for callers that cannot allocate
+ * device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc) and therefore
+ * cannot bring a workspace.  The partial sums live in a 2 MiB file-scope device array inside the library (one copy per
+ * GPU, held until the process ends; its address is looked up with hipGetSymbolAddress at the first call on each
+ * device, which must not itself be under stream capture).  Calls no hipMalloc / hipFree.  N > GZSL_COLSUM_STATIC_MAX_N
+ * is rejected with GZSL_ETOOBIG.  All calls on one GPU share the array: two calls that overlap on the same GPU (other
+ * streams or threads) race; nothing needs clearing between calls (every word read is written first by the same call). */
+#define GZSL_COLSUM_STATIC_MAX_N 8192
+#define GZSL_ETOOBIG 1002
+int gzsl_colsum_static(const float* x, float* out, long long M, int N, int ld, void* stream); /* out[n] += sum_m x[m*ld+n] */
 /* conv_modules.0.weight [F,E,k] -> Wp[f][j*E+e] (forward GEMM operand) and Wflip[e][j'*F+f] = W[f][e][k-1-j'] (data grad) */
 int gzsl_conv_weight_pack(const float* W, float* Wp, float* Wflip, int F, int E, int k, void* stream);
 

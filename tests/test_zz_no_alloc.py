@@ -1,0 +1,56 @@
+"""Allocation-free entry point (gzsl_colsum_static) against the existing workspace entry point (gzsl_colsum_ws).
+
+Both run the same two kernels over the same row-block partition (the static scratch is never the limiting size at
+these shapes), so the results must be IDENTICAL bit for bit -- a stricter bar than the fp32 tolerance the column sums
+are otherwise held to.  Two calls in a row share the library's per-GPU scratch array: the second, smaller one must not
+see anything of the first.  Collected last (test_zz_*): the round-end run uses `pytest -x`.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _both(ops, M, N, ld, seed):
+    from gzsl_text_amd import hip
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(rs.standard_normal((M, ld)).astype(np.float32)).to(DEV)[:, :N]
+    out0 = torch.from_numpy(rs.standard_normal(N).astype(np.float32)).to(DEV)
+    want = ops.colsum(x, out=out0.clone())               # gzsl_colsum_ws (M >= 4096) with a torch-allocated workspace
+    torch.cuda.synchronize()
+    got = out0.clone()
+    n_alloc_pre = torch.cuda.memory_stats().get('allocation.all.allocated', 0)
+    lib = hip.load()
+    rc = lib.gzsl_colsum_static(x.data_ptr(), got.data_ptr(), M, N, x.stride(0), hip.stream())  # straight through the C ABI
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_stats().get('allocation.all.allocated', 0) == n_alloc_pre  # torch's allocator untouched
+    ref = out0.double().cpu() + x.double().cpu().sum(0)
+    assert float((got.double().cpu() - ref).abs().max()) <= 2e-5 * np.sqrt(M) + 1e-5 * float(ref.abs().max())
+    assert torch.equal(got, want), float((got - want).abs().max())
+    return got
+
+
+def test_colsum_static_matches_workspace_entry_point_twice_in_a_row():
+    from gzsl_text_amd.ops_hip import HipOps
+    ops = HipOps()
+    _both(ops, 20000, 200, 200, 1)     # 157 row blocks x 200 columns of partial sums in the scratch array
+    _both(ops, 5000, 36, 64, 2)        # smaller, strided, scalar-load path: 40 row blocks; stale partials must not leak
+    _both(ops, 300, 100, 100, 3)       # few rows: the atomic path, scratch unused
+
+
+def test_colsum_static_rejects_sizes_beyond_its_maximum():
+    from gzsl_text_amd import hip
+    lib = hip.load()
+    x = torch.zeros(8, 8200, device=DEV)
+    out = torch.zeros(8200, device=DEV)
+    assert lib.gzsl_colsum_static(x.data_ptr(), out.data_ptr(), 8, 8200, 8200, hip.stream()) == hip.ETOOBIG
+    with pytest.raises(RuntimeError, match='maximum'):
+        hip.call('gzsl_colsum_static', x.data_ptr(), out.data_ptr(), 8, 8200, 8200)
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0
+    assert isinstance(ctypes.c_int(hip.ETOOBIG).value, int)
