@@ -469,7 +469,10 @@ __device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NARR], float* st
 // computes S = Q.K^T, P, the dropout mask and dK, the V-role wave dP = dO.V^T and dV.  They exchange the 16x16 Pd and
 // dP tiles (same lane layout: one 16-byte LDS store and load per lane) across one extra barrier per step; each
 // holds ONE accumulator array, so the workgroup runs 8 waves = two per SIMD.
-template <int ES, int NFT, int NW, int G, bool PAIR>
+// DROP: dropout on (compile-time: a runtime test splits the softmax block into one basic block per score element).
+// (Measured and rejected: letting waves 4.. run the previous step's dQ tile product at the START of their step, so that
+// the two waves of a SIMD are not in the same phase at the same time, cost +5.6 % at E = 100 and +7.5 % at E = 200.)
+template <int ES, int NFT, int NW, int G, bool PAIR, bool DROP>
 __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) {
     using P = BwdLds<ES, NFT, NW, PAIR>;
     constexpr int NWV = P::NWV;
@@ -737,8 +740,10 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
     };
 
     int l0_p1 = 0, l0_p2 = 0;  // first labels of the previous two steps
-    for (int it = 0; it < nsteps; ++it) {
-        const int cur = it & 1;
+    // The step is instantiated twice, once per tile buffer: every LDS address is then (lane constant) + (immediate); with a
+    // runtime buffer index the compiler rebuilt ~40 vector addresses per step (vector ALU time is matrix time here).
+    auto step_body = [&](auto CURC, const int it) {
+        constexpr int cur = decltype(CURC)::value;
         const int l0 = step_of(it) * BWD_BL;
         const bool more = it + 1 < nsteps;
         if (more && !(GZ_ABL & 8)) prefetch(step_of(it + 1));  // in flight during the whole step
@@ -859,7 +864,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
                 for (int r = 0; r < 4; ++r) {
                     float p = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
                     float dsc = 1.f;
-                    if (a.thresh && !(GZ_ABL & 4))
+                    if (DROP && !(GZ_ABL & 4))
                         dsc = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
                     pd[r] = p * dsc;
                     ds[r] = p * ((d0[r] + d1[r]) * dsc - del4[r]);
@@ -932,7 +937,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
                 for (int r = 0; r < 4; ++r) {
                     pr[r] = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
                     dsc[r] = 1.f;
-                    if (a.thresh) dsc[r] = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
+                    if (DROP) dsc[r] = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
                     pdv[r] = pr[r] * dsc[r];
                 }
                 *reinterpret_cast<f32x4*>(xch_pd) = pdv;
@@ -1013,6 +1018,10 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
         l0_p2 = l0_p1;
         l0_p1 = l0;
         __syncthreads();
+    };
+    for (int it = 0; it < nsteps; it += 2) {
+        step_body(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nsteps) step_body(std::integral_constant<int, 1>{}, it + 1);
     }
     if (nsteps > 0 && !(GZ_ABL & 1)) {  // drain: dQ of the last step, flushes of the last two
         const int last = (nsteps - 1) & 1;
@@ -1064,8 +1073,11 @@ static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     const dim3 grid(a.B * nTT * a.nsplit), block(P::NWV * 64);
     const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 &&
                      (((uintptr_t)a.Q | (uintptr_t)a.dO | (uintptr_t)a.PX | (uintptr_t)a.X) & 15) == 0;
-    if (vec) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4, PAIR>), grid, block, (size_t)P::floats * 4, st, a);
-    else hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1, PAIR>), grid, block, (size_t)P::floats * 4, st, a);
+    const size_t smem = (size_t)P::floats * 4;
+    if (vec && a.thresh) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4, PAIR, true>), grid, block, smem, st, a);
+    else if (vec) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4, PAIR, false>), grid, block, smem, st, a);
+    else if (a.thresh) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1, PAIR, true>), grid, block, smem, st, a);
+    else hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1, PAIR, false>), grid, block, smem, st, a);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
