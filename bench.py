@@ -1,18 +1,26 @@
 """Headline benchmark: train notes/sec of the base feature extractor (encoder + label attention + LDAM, fwd+bwd+Adam).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 600 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is what train_base.py:103-113 does per minibatch: zero_grad, model.forward (train mode: both dropouts on),
 loss.mean().backward(), Adam(lr 1e-3, wd 1e-5).step().  Inputs are resident in HBM before the timed region.
-Workload at N=1: BASELINE.json configs[1] (B=16, T=2500, E=H=100, L=9000, N=12000 nodes, V=50001, F=200, k=10, C=2).
-At N>1 the label dimension is sharded L/N per rank and the global batch grows to 16*N (each rank encodes 16 notes and
-attends 16*N notes x L/N labels: per-GPU work is fixed -> "weak" scaling).
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel: label_attn_bwd, timed with
-events on the launch stream inside the timed region; algorithmic FLOPs as DESIGN.md states them) and, at N=1,
-`cpu_baseline` (the numpy oracle timed on the host cores on a bounded sample of the same workload).
+--config cfg2 (default): BASELINE.json configs[1] (B=16, T=2500, E=H=100, L=9000, N=12000 nodes, V=50001, F=200, k=10,
+    C=2).  At N>1 the label dimension is sharded L/N per rank and the global batch grows to 16*N (each rank encodes 16
+    notes and attends 16*N notes x L/N labels: per-GPU work is fixed -> "weak" scaling).
+--config cfg3: BASELINE.json configs[2] (T=4000, global batch fixed at 16, L=9000 sharded L/N per rank -> "strong").
+--config real: cfg2 with E=H=200 (the width the reference's drivers build from the shipped resources).
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      dominant kernel (label_attn_bwd), timed with events on the launch stream INSIDE the timed region;
+                .also: forward attention, whole step, at N=1 the same numbers at E=H=200 (`real_e200`, separate short
+                pass) and achieved GB/s of every HBM-bound kernel of the step (`hbm`, separate short pass; algorithmic
+                bytes as SURVEY.md 8d / DESIGN.md 4 state them, peak 8 TB/s)
+  cpu_baseline  (N=1) the numpy oracle timed on the host cores on a bounded sample of the same workload
+  comm          (N>1) per collective: ms per step the launching stream sat blocked on it (exposed communication) and
+                bytes per call; plus ms/step of a short pass with the own-notes-first ordering switched the other way.
 """
 import argparse
 import json
@@ -27,14 +35,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s is what a float4 copy reaches)
+
+CONFIGS = {
+    'cfg2': dict(T=2500, E=100, weak=True, name='BASELINE.json configs[1]'),
+    'cfg3': dict(T=4000, E=100, weak=False, name='BASELINE.json configs[2]'),
+    'real': dict(T=2500, E=200, weak=True, name='BASELINE.json configs[1] at the drivers\' real width E=H=200'),
+}
 
 
-def workload(args, world):
-    from tests.golden import synth
-    B = args.batch_per_gpu * world
-    case = synth.synth_base(seed=1234, B=B, T=args.T, E=args.E, H=args.E, L=args.L, N=args.N, Td=30, V=args.V, F=200,
+def workload(args, world, E=None):
+    from gzsl_text_amd.utils import synth
+    B = args.batch_per_gpu * world if args.weak else args.batch_per_gpu
+    E = args.E if E is None else E
+    return synth.synth_base(seed=1234, B=B, T=args.T, E=E, H=E, L=args.L, N=args.N, Td=30, V=args.V, F=200,
                             labels_per_note=15, emb_scale=0.1, zipf=True)
-    return case
 
 
 def algorithmic_flops(d, B, L_local):
@@ -53,27 +68,29 @@ def step_flops(d, B):
 
 
 def measured_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this script).  FETCH_SIZE is doubled as MI355X_MICROARCH.md
-    prescribes for gfx950; returns None when no measurement is committed (bench.py cannot run the profiler itself)."""
-    fn = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(fn) as f:
-            d = json.load(f)[kernel]
-        return (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json,
+    newest round first: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this script).  FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; None when no measurement is committed (bench.py cannot run the profiler)."""
+    for rnd in ('r02', 'r01'):
+        fn = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic.json')
+        try:
+            with open(fn) as f:
+                d = json.load(f)[kernel]
+            return (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0, os.path.basename(fn)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 class KernelTimer:
-    """Wraps HipOps.attn_fwd / attn_bwd with event pairs on the launch stream (torch's current stream)."""
+    """Wraps HipOps methods with event pairs on the launch stream (torch's current stream at the call)."""
 
-    def __init__(self, ops):
+    def __init__(self, ops, names):
         self.ops = ops
-        self.events = {'attn_fwd': [], 'attn_bwd': []}
+        self.events = {n: [] for n in names}
         self.enabled = False
-        ops.attn_fwd = self._wrap('attn_fwd', ops.attn_fwd)
-        ops.attn_bwd_main = self._wrap('attn_bwd', ops.attn_bwd_main)  # the label_attn_bwd launch alone
+        for n in names:
+            setattr(ops, n, self._wrap(n, getattr(ops, n)))
 
     def _wrap(self, name, fn):
         def inner(*a, **k):
@@ -91,10 +108,75 @@ class KernelTimer:
         ev = self.events[name]
         return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
 
+    def total_ms(self, name, steps):
+        ev = self.events[name]
+        return float(np.sum([a.elapsed_time(b) for a, b in ev])) / steps if ev else None
+
+
+def hbm_bytes(d, B, nnz):
+    """Algorithmic bytes PER STEP of the HBM-bound kernels (SURVEY.md 8d formulas; atomics counted as the bytes added),
+    keyed by the HipOps method that launches them; `calls` = launches per step the bytes are summed over."""
+    T, E, F, L, D, N, H, V, Td = d['T'], d['E'], d['F'], d['L'], d['D'], d['N'], d['H'], d['V'], d['Td']
+    BT = B * T
+    return {
+        'emb_gather': BT * (8 + 4 + 2 * E * 4),
+        'emb_scatter_add_': BT * (8 + 4) + 2 * BT * E * 4,
+        'label_avg': N * Td * (8 + 4) + N * Td * E * 4 + N * E * 4,
+        'label_avg_bwd_': N * Td * (8 + 4) + N * E * 4 + N * Td * E * 4,
+        'spmm': 4 * (nnz * (8 + H * 4) + 2 * N * H * 4),                   # 2 forward + 2 adjoint launches
+        'gru_gate_fwd': 2 * 8 * N * H * 4,                                 # reads gi, gh [N,3H], h; writes hn
+        'gru_gate_bwd': 2 * 15 * N * H * 4,                                # + dhn in, dgi, dgh, dh out
+        'logits_fwd': B * L * D * 4 + L * D * 4 + B * L * 4,
+        'logits_bwd': 2 * B * L * D * 4 + 2 * L * D * 4 + B * L * 4,
+        'attn_delta': 2 * B * L * F * 4 + B * L * 4,
+        'ldam_bce': 3 * B * L * 4 + L * 4,
+    }
+
+
+def hbm_pass(model, step, timer_ops, d, B, steps=5):
+    """Short pass after the timed region: event-time every HBM-bound kernel of the step and report achieved GB/s."""
+    names = ['emb_gather', 'emb_scatter_add_', 'label_avg', 'label_avg_bwd_', 'spmm', 'gru_gate_fwd', 'gru_gate_bwd',
+             'logits_fwd', 'logits_bwd', 'ldam_bce']
+    ops = timer_ops
+    t = KernelTimer(ops, names)
+    # attn_delta is launched inside HipOps.attn_bwd: time it through the C-ABI call table
+    from gzsl_text_amd import ops_hip
+    orig_call = ops_hip.call
+    delta_ev = []
+
+    def call(name, *a):
+        if name != 'gzsl_attn_delta' or not t.enabled:
+            return orig_call(name, *a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_call(name, *a)
+        e1.record()
+        delta_ev.append((e0, e1))
+    ops_hip.call = call
+    try:
+        t.enabled = True
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        t.enabled = False
+    finally:
+        ops_hip.call = orig_call
+    nnz = int(model._graph_buffers().csr[1].numel())
+    by = hbm_bytes(d, B, nnz)
+    out = {}
+    for n in names + ['attn_delta']:
+        ms = (float(np.sum([a.elapsed_time(b) for a, b in delta_ev])) / steps) if n == 'attn_delta' else t.total_ms(n, steps)
+        if not ms:
+            continue
+        gbs = by[n] / (ms * 1e-3) / 1e9
+        out[n] = {'bytes_per_step': int(by[n]), 'ms_per_step': ms, 'GBps': gbs, 'frac_of_8TBps': gbs / PEAK_HBM_GBS}
+    return out
+
 
 def cpu_baseline(case, args):
     """Oracle (numpy restatement) timed on the host cores on a bounded sample of the same workload: the 16 notes of the
-    N=1 batch, fwd+bwd over all labels incl. the label encoder, three passes (~10-15 s on the box's 16-core share)."""
+    N=1 batch, fwd+bwd over all labels incl. the label encoder, three passes (~10-15 s on the box's 16-core share).
+    The optimizer step of the GPU leg is NOT part of this leg (elementwise over 5.3 M parameters: noise here)."""
     from oracle import base_model as om
     d = case['dims']
     nb, reps = min(16, d['B']), 3
@@ -104,26 +186,89 @@ def cpu_baseline(case, args):
     for _ in range(reps):
         om.base_forward_backward(case['params'], case['bufs'], x, y, mask, d['L'], margin, 2.0, drop_seed=1234, l_chunk=1500)
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
-    return {'value': nb * reps / dt, 'unit': 'notes/s', 'cores': cores, 'kind': 'port',
+    threads = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
+    try:  # the thread count numpy's BLAS actually runs with
+        from threadpoolctl import threadpool_info
+        blas = [p['num_threads'] for p in threadpool_info() if p.get('user_api') == 'blas']
+        if blas:
+            threads = max(blas)
+    except Exception:
+        pass
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:
+        physical = None
+    return {'value': nb * reps / dt, 'unit': 'notes/s', 'cores': threads, 'kind': 'port',
+            'physical_cores_on_host': physical, 'logical_cpus_on_host': os.cpu_count(),
             'sample': f'{reps} passes over {nb} notes of the same workload (T={d["T"]}, L={d["L"]}, N={d["N"]}), fwd+bwd incl. '
-                      f'label encoder (no optimizer step), numpy fp32 oracle, BLAS threads={cores}, {dt:.1f} s'}
+                      f'label encoder (no optimizer step), numpy fp32 oracle, BLAS threads={threads}, {dt:.1f} s'}
+
+
+def attention_lines(timer, d, B, L_local):
+    bwd_ms, fwd_ms = timer.mean_ms('attn_bwd_main'), timer.mean_ms('attn_fwd')
+    fl = algorithmic_flops(d, B, L_local)
+    return bwd_ms, fwd_ms, fl
+
+
+def real_e200_pass(args, dev, steps=5):
+    """The same step at E=H=200 (what the reference's drivers build from the shipped resources), N=1, short pass."""
+    from gzsl_text_amd.modules.common_module import get_optimizer
+    from gzsl_text_amd.utils import synth
+    case = workload(args, 1, E=200)
+    d = case['dims']
+    model = synth.build_model(case, device=dev)
+    model.train()
+    model.set_dropout_seed(1234)
+    x, y, mask = synth.batch_tensors(case, dev)
+    opt = get_optimizer(1e-3, model, weight_decay=1e-5)
+    timer = KernelTimer(model._engine().ops, ['attn_fwd', 'attn_bwd_main'])
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        _, loss = model(x, y, mask)
+        loss.mean().backward()
+        opt.step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    bwd_ms, fwd_ms, fl = attention_lines(timer, d, d['B'], d['L'])
+    return {'config': f'E=H=200, D=400, otherwise the N=1 workload; {steps} steps', 'ms_per_step': dt * 1e3,
+            'notes_per_s': d['B'] / dt,
+            'label_attn_bwd_kernel': {'ms_per_launch': bwd_ms, 'achieved': 2 * fl / (bwd_ms * 1e-3) / 1e12,
+                                      'frac': 2 * fl / (bwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+            'label_attn_fwd_kernel': {'ms_per_launch': fwd_ms, 'achieved': fl / (fwd_ms * 1e-3) / 1e12,
+                                      'frac': fl / (fwd_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+            'whole_step_frac': step_flops(d, d['B']) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch-per-gpu', type=int, default=16)
-    ap.add_argument('--T', type=int, default=2500)
-    ap.add_argument('--E', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=600)   # ~5 s of GPU work at N=1: longer than the driver's smi sampling period
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default=os.environ.get('GZSL_BENCH_CONFIG', 'cfg2'))
+    ap.add_argument('--batch-per-gpu', type=int, default=16, help='notes per GPU (weak configs) / global batch (cfg3)')
+    ap.add_argument('--T', type=int, default=None)
+    ap.add_argument('--E', type=int, default=None)
     ap.add_argument('--L', type=int, default=9000)
     ap.add_argument('--N', type=int, default=12000)
     ap.add_argument('--V', type=int, default=50001)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the short post-passes (E=200 line, HBM kernels, comm A/B)')
     ap.add_argument('--no-optimizer', action='store_true', help='time fwd+bwd only (diagnostic, not the metric)')
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.T = cfg['T'] if args.T is None else args.T
+    args.E = cfg['E'] if args.E is None else args.E
+    args.weak = cfg['weak']
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -148,18 +293,19 @@ def main():
             dist.init_process_group(backend)
 
     from gzsl_text_amd.modules.common_module import get_optimizer
-    from tests import helpers
+    from gzsl_text_amd.utils import synth
 
     case = workload(args, world)
     d = case['dims']
-    model = helpers.build_model(case, device=dev)
+    model = synth.build_model(case, device=dev)
     model.train()
     model.set_dropout_seed(1234)
     if dist_on:
         model.enable_label_sharding()
-    x, y, mask = helpers.batch_tensors(case, dev)
+    x, y, mask = synth.batch_tensors(case, dev)
     opt = get_optimizer(1e-3, model, weight_decay=1e-5)
-    timer = KernelTimer(model._engine().ops)
+    ops = model._engine().ops
+    timer = KernelTimer(ops, ['attn_fwd', 'attn_bwd_main'])  # attn_bwd_main = the label_attn_bwd launch alone
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -190,6 +336,8 @@ def main():
         note(f'warmup step {i} issued')
     fence()
     note('warmup done')
+    if dist_on:
+        model._shard.start_profile()
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,7 +345,10 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    comm = None
     if dist_on:
+        comm = model._shard.profile_summary(args.steps)
+        model._shard.prof = None
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -205,23 +356,27 @@ def main():
 
     B = d['B']
     L_local = d['L'] // world + (1 if rank < d['L'] % world else 0)
-    bwd_ms, fwd_ms = timer.mean_ms('attn_bwd'), timer.mean_ms('attn_fwd')
-    fl_fwd = algorithmic_flops(d, B, L_local)
-    ach = 2 * fl_fwd / (bwd_ms * 1e-3) / 1e12
+    bwd_ms, fwd_ms, fl_fwd = attention_lines(timer, d, B, L_local)
+    # (the own-notes-first ordering splits each attention launch into note blocks: sum the pieces of a step)
+    n_bwd = len(timer.events['attn_bwd_main']) / max(args.steps, 1)
+    fwd_ms *= len(timer.events['attn_fwd']) / max(args.steps, 1)
+    ach = 2 * fl_fwd / (bwd_ms * n_bwd * 1e-3) / 1e12
+    traffic, traffic_file = measured_traffic('label_attn_bwd_kernel') if (world == 1 and args.config == 'cfg2') else (None, None)
+    per_gpu = f'{args.batch_per_gpu}/GPU' if args.weak else 'fixed'
     out = {
         'metric': 'train notes/sec (enc+label-attn+LDAM fwd/bwd)', 'value': B * args.steps / dt, 'unit': 'notes/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'BASELINE.json configs[1]: base model fwd+bwd+Adam, B={B} (16/GPU), T={d["T"]}, '
+        'higher_is_better': True, 'scaling': 'weak' if args.weak else 'strong', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': f'{cfg["name"]}: base model fwd+bwd+Adam, B={B} ({per_gpu}), T={d["T"]}, '
                                f'E=H={d["E"]}, F=200, k=10, L={d["L"]} ({L_local}/GPU), N={d["N"]}, V={d["V"]}, '
                                f'train mode (emb dropout .5, attn dropout .2), LDAM C=2, graph_encoder=gate',
                    'global_batch': B, 'seq_len': d['T'], 'parallelism': f'label-shard x{world}' if world > 1 else 'single'},
         'roofline': {'bound': 'mfma', 'kernel': 'label_attn_bwd_kernel', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS,
-                     'traffic': measured_traffic('label_attn_bwd_kernel') if world == 1 else None,
-                     'traffic_note': 'bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_pmc_traffic.json '
+                     'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                     'traffic_note': f'bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/{traffic_file} '
                                      '(rocprofv3 PMC passes of this command at N=1; not re-measured in this run)',
-                     'ms_per_launch': bwd_ms,
+                     'ms_per_launch': bwd_ms * n_bwd, 'launches_per_step': n_bwd,
                      'algorithmic_flops_per_launch': 2 * fl_fwd,
                      'also': {'label_attn_fwd_kernel': {'ms_per_launch': fwd_ms,
                                                         'achieved': fl_fwd / (fwd_ms * 1e-3) / 1e12,
@@ -231,6 +386,39 @@ def main():
                                              'frac': step_flops(d, B) / world / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}},
         'loss': float(loss.detach()),
     }
+    if dist_on:
+        out['comm'] = {'world_size_seen_by_rccl': dist.get_world_size(), 'backend': dist.get_backend(),
+                       'own_notes_first': bool(model._shard.own_first),
+                       'collectives': comm,
+                       'note': 'exposed_ms_per_step = event-timed time the launching stream sat blocked on the collective '
+                               '(rank 0); no scaling curve has been measured by the builder (one-GPU boxes only)'}
+        if not args.no_extras and world > 1 and model._shard.batch_split(B) is not None:
+            # A/B: the other ordering, a short pass (max over ranks)
+            sh = model._shard
+            sh.own_first = not sh.own_first
+            n_ab = max(3, min(20, args.steps))
+            for _ in range(2):
+                step()
+            fence()
+            sh.start_profile()
+            t1 = time.perf_counter()
+            for _ in range(n_ab):
+                step()
+            fence()
+            dt_ab = time.perf_counter() - t1
+            tt = torch.tensor([dt_ab], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out['comm']['other_ordering'] = {'own_notes_first': bool(sh.own_first), 'steps': n_ab,
+                                             'ms_per_step': float(tt.item()) / n_ab * 1e3,
+                                             'collectives': sh.profile_summary(n_ab)}
+            sh.prof = None
+            sh.own_first = not sh.own_first
+    if world == 1 and not args.no_extras:
+        out['roofline']['also']['hbm'] = hbm_pass(model, step, ops, d, B)
+        if args.config == 'cfg2' and args.E == 100:
+            del model, opt
+            torch.cuda.empty_cache()
+            out['roofline']['also']['real_e200'] = real_e200_pass(args, dev)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(case, args)

@@ -161,14 +161,40 @@ class BaseEngine:
                              row_offset=row_offset)
 
     # ------------------------------------------------------------------------------------------ attention + head
-    def head_fwd(self, P, X, PX, Q, clf, l_offset, L_total, seed, training):
-        """icd_modules.py:137-142,159,177-182 for the label rows [l_offset, l_offset + len(Q))."""
+    def attn_fwd_block(self, PX, X, Q, l_offset, L_total, seed, training, O, lse, c0):
+        """Attention of the note block [c0, c0 + len(PX)) of a batch into O[c0:], lse[c0:].  The dropout hash is keyed
+        on row = note * L_total + label, so a block's global note index travels in the label offset."""
+        n = PX.shape[0]
+        self.ops.attn_fwd(PX, X, Q, l_offset + c0 * L_total, L_total, seed, P_ATTN_DROP if training else 0.0,
+                          out=(O[c0:c0 + n], lse[c0:c0 + n]))
+
+    def attn_bwd_block(self, dO, O, lse, PX, X, Q, c0, c1, l_offset, L_total, seed, training, dPX, dX, dQ):
+        """Backward of `attn_fwd_block` for notes [c0, c1): adds into dPX / dX (tensors of THAT block) and dQ."""
+        self.ops.attn_bwd(dO[c0:c1], O[c0:c1], PX, X, Q, lse[c0:c1], l_offset + c0 * L_total, L_total, seed,
+                          P_ATTN_DROP if training else 0.0, dPX, dX, dQ)
+
+    def head_fwd(self, P, X, PX, Q, clf, l_offset, L_total, seed, training, attn=None):
+        """icd_modules.py:137-142,159,177-182 for the label rows [l_offset, l_offset + len(Q)).  attn = (O, lse) when
+        the caller has already run the attention (note block by note block)."""
         ops = self.ops
-        O, lse = ops.attn_fwd(PX, X, Q, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0)
+        if attn is None:
+            O, lse = ops.attn_fwd(PX, X, Q, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0)
+        else:
+            O, lse = attn
         B, L, F_ = O.shape
         direct = ops.linear(O.view(B * L, F_), P['output_proj.weight'], P['output_proj.bias']).view(B, L, -1)
         logits = ops.logits_fwd(direct, clf)
         return O, lse, direct, logits
+
+    def head_bwd_pre(self, dlogits, O, direct, clf, P):
+        """Classifier + output_proj data gradient: returns (dclf [L,D], dO [B,L,F], pending weight-gradient operands)."""
+        ops = self.ops
+        B, L, F_ = O.shape
+        D = direct.shape[2]
+        ddirect, dclf = ops.logits_bwd(direct, clf, dlogits, need_ddirect=True)
+        dd2 = ddirect.view(B * L, D)
+        dO = ops.mm(dd2, P['output_proj.weight']).view(B, L, F_)
+        return dclf, dO, (dd2, O.view(B * L, F_))
 
     def head_bwd(self, dlogits, O, lse, direct, X, PX, Q, clf, l_offset, L_total, seed, training, P, G,
                  dX, dPX, dQ, need_encoder_grads=True, defer_wgrad=False):
@@ -178,18 +204,14 @@ class BaseEngine:
         `head_wgrad(pending, G)`: they depend on nothing downstream, so the sharded path runs them while the
         reduce-scatter of dX / dPX is on the wire."""
         ops = self.ops
-        B, L, F_ = O.shape
-        D = direct.shape[2]
-        ddirect, dclf = ops.logits_bwd(direct, clf, dlogits, need_ddirect=need_encoder_grads)
         if not need_encoder_grads:
+            _, dclf = ops.logits_bwd(direct, clf, dlogits, need_ddirect=False)
             return (dclf, None) if defer_wgrad else dclf
-        dd2 = ddirect.view(B * L, D)
-        O2 = O.view(B * L, F_)
+        dclf, dO, pending = self.head_bwd_pre(dlogits, O, direct, clf, P)
         if not defer_wgrad:
-            self.head_wgrad((dd2, O2), G)
-        dO = ops.mm(dd2, P['output_proj.weight']).view(B, L, F_)
+            self.head_wgrad(pending, G)
         ops.attn_bwd(dO, O, PX, X, Q, lse, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0, dPX, dX, dQ)
-        return (dclf, (dd2, O2)) if defer_wgrad else dclf
+        return (dclf, pending) if defer_wgrad else dclf
 
     def head_wgrad(self, pending, G):
         if pending is None:

@@ -64,6 +64,7 @@ class _BaseModelFn(torch.autograd.Function):
         mask_c = None if mask is None else mask.contiguous().to(torch.float32)
         l0, l1 = (0, L) if sh is None else sh.label_range(L)
         bs = None if sh is None else sh.batch_split(B)
+        attn = None
         if bs is not None:
             # this rank encodes its B/P notes; X and PX then travel to every rank
             b0, b1 = bs
@@ -74,9 +75,23 @@ class _BaseModelFn(torch.autograd.Function):
                                          seed, training, row_offset=b0 * x.shape[1])
             X, hx = sh.all_gather_batch_start(Xl)
             PX, hp = sh.all_gather_batch_start(PXl)
-            hx.wait()
-            hp.wait()
-            beside.join()
+            if sh.own_first and sh.world > 1:
+                # the attention of this rank's own notes needs nothing from the wire: run it under the gathers
+                beside.join()
+                Ql = avg[l0:l1]
+                O = torch.empty((B, l1 - l0, Xl.shape[2]), dtype=torch.float32, device=Xl.device)
+                lse = torch.empty((B, l1 - l0), dtype=torch.float32, device=Xl.device)
+                eng.attn_fwd_block(PXl, Xl, Ql, l0, L, seed, training, O, lse, b0)
+                sh.wait(hx, 'fwd_all_gather_X', X)
+                sh.wait(hp, 'fwd_all_gather_PX', PX)
+                for c0, c1 in ((0, b0), (b1, B)):
+                    if c1 > c0:
+                        eng.attn_fwd_block(PX[c0:c1], X[c0:c1], Ql, l0, L, seed, training, O, lse, c0)
+                attn = (O, lse)
+            else:
+                sh.wait(hx, 'fwd_all_gather_X', X)
+                sh.wait(hp, 'fwd_all_gather_PX', PX)
+                beside.join()
         else:
             beside = _Beside(x)
             with beside:
@@ -85,7 +100,7 @@ class _BaseModelFn(torch.autograd.Function):
             beside.join()
         Q = avg[l0:l1]
         clf = graph[l0:l1]
-        O, lse, direct, logits_l = eng.head_fwd(P, X, PX, Q, clf, l0, L, seed, training)
+        O, lse, direct, logits_l = eng.head_fwd(P, X, PX, Q, clf, l0, L, seed, training, attn=attn)
         margin = mod.class_margin
         y_l = y if (l0 == 0 and l1 == y.shape[1]) else y[:, l0:l1]
         y_l = y_l.contiguous().to(torch.float32)
@@ -93,7 +108,7 @@ class _BaseModelFn(torch.autograd.Function):
         loss, dlogits, _ = eng.ops.ldam_bce(logits_l, y_l, m_l, mod.C, 1.0 / B, need_grad=need_grad)
         if sh is not None:
             logits = sh.all_gather_labels(logits_l, L)
-            sh.all_reduce_(loss)
+            sh.all_reduce_(loss, 'loss_all_reduce')
         else:
             logits = logits_l
         if need_grad:
@@ -120,7 +135,18 @@ class _BaseModelFn(torch.autograd.Function):
         davg = torch.zeros(avg_shape, dtype=torch.float32, device=X.device)
         dgraph = torch.zeros(graph_shape, dtype=torch.float32, device=X.device)
         pending = None
-        if bs is not None:
+        own = None
+        if bs is not None and sh.own_first and sh.world > 1:
+            # other ranks' notes first; the reduce-scatter then starts with a zero own block, and the own block's
+            # partial (computed while it is on the wire) is added to the scattered result
+            b0, b1 = bs
+            dclf, dO, pending = eng.head_bwd_pre(dlogits, O, direct, clf, P)
+            for c0, c1 in ((0, b0), (b1, X.shape[0])):
+                if c1 > c0:
+                    eng.attn_bwd_block(dO, O, lse, PX[c0:c1], X[c0:c1], Q, c0, c1, l0, L, seed, training, dPX[c0:c1],
+                                       dX[c0:c1], davg[l0:l1])
+            own = (dO, torch.zeros_like(dX[b0:b1]), torch.zeros_like(dPX[b0:b1]))
+        elif bs is not None:
             dclf, pending = eng.head_bwd(dlogits, O, lse, direct, X, PX, Q, clf, l0, L, seed, training, P, G, dX, dPX,
                                          davg[l0:l1], defer_wgrad=True)
         else:
@@ -132,12 +158,19 @@ class _BaseModelFn(torch.autograd.Function):
             b0, b1 = bs
             dXl, hx = sh.reduce_scatter_batch_start(dX)
             dPXl, hp = sh.reduce_scatter_batch_start(dPX)
+            if own is not None:
+                dO, dX_own, dPX_own = own
+                eng.attn_bwd_block(dO, O, lse, PX[b0:b1], X[b0:b1], Q, b0, b1, l0, L, seed, training, dPX_own, dX_own,
+                                   davg[l0:l1])
             beside = _Beside(dX)
-            with beside:  # beside the reduce-scatters and the note encoder's backward
+            with beside:  # beside the reduce-scatters and the note encoder's backward (davg is complete by now)
                 eng.label_bwd(davg, dgraph, lcache, P, gb, G)
             eng.head_wgrad(pending, G)  # output_proj weight gradient: compute for the time the reduce-scatter is on the wire
-            hx.wait()
-            hp.wait()
+            sh.wait(hx, 'bwd_reduce_scatter_dX', dX)
+            sh.wait(hp, 'bwd_reduce_scatter_dPX', dPX)
+            if own is not None:
+                dXl.add_(dX_own)
+                dPXl.add_(dPX_own)
             eng.encoder_bwd(dXl, dPXl, X[b0:b1], PX[b0:b1], e, x[b0:b1].contiguous(),
                             None if mask_c is None else mask_c[b0:b1].contiguous(), seed, training, P, G,
                             row_offset=b0 * x.shape[1])
@@ -145,8 +178,8 @@ class _BaseModelFn(torch.autograd.Function):
         elif sh is not None:
             # replicated encoder: sum the shards' partial dX||dPX, then every rank runs the same encoder backward;
             # its (identical) parameter gradients must not be summed again -> scale by 1/P before the label side adds
-            sh.all_reduce_(dX)
-            sh.all_reduce_(dPX)
+            sh.all_reduce_(dX, 'bwd_all_reduce_dX')
+            sh.all_reduce_(dPX, 'bwd_all_reduce_dPX')
             eng.encoder_bwd(dX, dPX, X, PX, e, x, mask_c, seed, training, P, G)
             for k in ('emb.embed.weight', 'conv_modules.0.weight', 'conv_modules.0.bias', 'proj.weight', 'proj.bias'):
                 G[k].mul_(1.0 / sh.world)
@@ -159,7 +192,7 @@ class _BaseModelFn(torch.autograd.Function):
             eng.encoder_bwd(dX, dPX, X, PX, e, x, mask_c, seed, training, P, G)
             beside.join()
         if sh is not None:
-            sh.all_reduce_(G.flat)
+            sh.all_reduce_(G.flat, 'grad_all_reduce')
         return (None, None, None, None, None) + tuple(G[k] if need else None for k, need in zip(names, ctx.needs))
 
 
@@ -271,8 +304,8 @@ class ConvLabelAttnModel(nn.Module):
         self._fwd_count += 1
         return s
 
-    def enable_label_sharding(self, group=None):
-        self._shard = LabelShard(group)
+    def enable_label_sharding(self, group=None, own_first=None):
+        self._shard = LabelShard(group, own_first=own_first)
         return self
 
     # ---------------------------------------------------------------------------------------------- reference API
@@ -354,32 +387,55 @@ class _GanModelFn(torch.autograd.Function):
         # y is NOT cut to eval_code_size: the reference (icd_modules.py:275) raises a shape error for targets wider than
         # the logits, and so does HipOps.ldam_bce
         B = x.shape[0]
+        x = x.contiguous()
         mask_c = None if mask is None else mask.contiguous().to(torch.float32)
-        X, PX, _ = eng.encoder_fwd(P, x.contiguous(), mask_c, seed, training)
+        sh = mod._shard
+        Lp = Q.shape[0]
+        # label sharding (finetune-time scoring over 8 GPUs, finetune.py:224-253): rank r owns rows [l0, l1) of the
+        # (possibly gathered) label list; the encoder is batch-split + all-gathered when the batch divides evenly
+        l0, l1 = (0, Lp) if sh is None else sh.label_range(Lp)
+        bs = None if sh is None else sh.batch_split(B)
+        if bs is not None:
+            b0, b1 = bs
+            Xl, PXl, _ = eng.encoder_fwd(P, x[b0:b1].contiguous(), None if mask_c is None else mask_c[b0:b1].contiguous(),
+                                         seed, training, row_offset=b0 * x.shape[1])
+            X, PX = sh.all_gather_batch(Xl), sh.all_gather_batch(PXl)
+        else:
+            X, PX, _ = eng.encoder_fwd(P, x, mask_c, seed, training)
+        if sh is not None:
+            Q, clf = Q[l0:l1].contiguous(), clf[l0:l1].contiguous()
+            y = y[:, l0:l1]
+            if margin is not None:
+                margin = margin[l0:l1].contiguous()
         # a label subset keeps its GLOBAL dropout coordinates only when it is the identity; a gathered subset is a
         # different attention problem in the reference too (fresh torch dropout mask), so rows are numbered locally
-        O, lse, direct, logits = eng.head_fwd(P, X, PX, Q, clf, 0, Q.shape[0], seed, training)
+        O, lse, direct, logits = eng.head_fwd(P, X, PX, Q, clf, l0, Lp, seed, training)
         loss, dlogits, _ = eng.ops.ldam_bce(logits, y.contiguous().to(torch.float32), margin, mod.C, 1.0 / B,
                                             need_grad=need_grad)
+        if sh is not None:
+            logits = sh.all_gather_labels(logits, Lp)
+            sh.all_reduce_(loss, 'loss_all_reduce')
         if need_grad:
             ctx.mod = mod
-            ctx.state = (direct, clf, dlogits, idx, fcw.shape)
+            ctx.state = (direct, clf, dlogits, idx, fcw.shape, l0)
         ctx.mark_non_differentiable(logits)
         return logits, loss
 
     @staticmethod
     def backward(ctx, _unused, dloss):
         mod = ctx.mod
-        direct, clf, dlogits, idx, fc_shape = ctx.state
+        direct, clf, dlogits, idx, fc_shape, l0 = ctx.state
         ctx.state = None
         eng = mod._engine()
         _, dclf = eng.ops.logits_bwd(direct, clf, dlogits * dloss, need_ddirect=False)
         dfc = torch.zeros(fc_shape, dtype=torch.float32, device=direct.device)
         n = dclf.shape[0]
         if idx is not None:
-            dfc.index_add_(0, idx[:n], dclf)
+            dfc.index_add_(0, idx[l0:l0 + n], dclf)
         else:
-            dfc[:n] = dclf
+            dfc[l0:l0 + n] = dclf
+        if mod._shard is not None:  # every rank holds the rows of its label range: sum to the full gradient
+            mod._shard.all_reduce_(dfc, 'grad_all_reduce')
         return None, None, None, None, None, None, dfc
 
 

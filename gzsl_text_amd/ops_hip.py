@@ -233,12 +233,17 @@ class HipOps:
              {None: 0, 'last': 0, 'max': 1, 'mean': 2}[pool_mode], Bg, H3 // 3)
 
     # ------------------------------------------------------------------------------------ attention + head + loss
-    def attn_fwd(self, PX, X, Q, l_offset, L_total, seed, p):
+    def attn_fwd(self, PX, X, Q, l_offset, L_total, seed, p, out=None):
+        """out = (O [B,L,F], lse [B,L]) contiguous views to fill (a note block of a larger batch), else allocated."""
         B, Tp, E = PX.shape
         F_ = X.shape[2]
         L = Q.shape[0]
-        O = torch.empty((B, L, F_), dtype=torch.float32, device=PX.device)
-        lse = torch.empty((B, L), dtype=torch.float32, device=PX.device)
+        if out is None:
+            O = torch.empty((B, L, F_), dtype=torch.float32, device=PX.device)
+            lse = torch.empty((B, L), dtype=torch.float32, device=PX.device)
+        else:
+            O, lse = out
+            assert tuple(O.shape) == (B, L, F_) and tuple(lse.shape) == (B, L)
         th, sc = drop_params(p)
         call('gzsl_label_attn_fwd', ptr(PX), ptr(X), ptr(Q), ptr(O), ptr(lse), B, Tp, E, F_, L, l_offset, L_total,
              seed & 0xFFFFFFFF, th, sc)

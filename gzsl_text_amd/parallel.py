@@ -17,6 +17,9 @@ When B is not divisible by P the encoder is replicated instead (every rank encod
 All ranks must hold identical parameters, draw the same batch and use the same dropout seed; the dropout hash is
 keyed on global (note, label, token) coordinates, so results do not depend on P.
 """
+import os
+from collections import defaultdict
+
 import torch
 import torch.distributed as dist
 
@@ -29,12 +32,18 @@ def partition(n, world, rank):
 
 
 class LabelShard:
-    def __init__(self, group=None):
+    def __init__(self, group=None, own_first=None):
         if not dist.is_initialized():
             raise RuntimeError('LabelShard needs torch.distributed to be initialised (one process per GPU)')
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # own-notes-first ordering (batch-split encoder only): the attention of the rank's OWN notes needs no
+        # communication, so it runs while the X / PX all-gather is on the wire (forward), and the other ranks' notes go
+        # first in backward so that the reduce-scatter starts before the own block is done.  Costs extra launches
+        # (DESIGN.md 6); off by default, GZSL_OWN_FIRST=1 or own_first=True switches it on.
+        self.own_first = (os.environ.get('GZSL_OWN_FIRST') == '1') if own_first is None else bool(own_first)
+        self.prof = None  # comm profile: tag -> list of (event before, event after, bytes); see start_profile()
         # RCCL ('nccl') moves device tensors directly.  Under gloo (CPU tests; rehearsals with ranks sharing a GPU)
         # device tensors are staged through host memory: gloo's own device path stalls on multi-MB tensors.
         self.stage = dist.get_backend(group) != 'nccl'
@@ -49,6 +58,34 @@ class LabelShard:
             out.copy_(o)
         else:
             fn(out, inp)
+        return out
+
+    # ---- communication profile (bench.py): how long the launching stream sat blocked on each collective -------------
+    def start_profile(self):
+        self.prof = defaultdict(list)
+
+    def _timed(self, tag, nbytes, fn):
+        """Brackets `fn` (a blocking wait on, or a synchronous call of, a collective) with events on the current stream:
+        their distance is the time that stream was held up by the collective, i.e. the EXPOSED communication."""
+        if self.prof is None or not torch.cuda.is_available():
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.prof[tag].append((e0, e1, int(nbytes)))
+        return r
+
+    def wait(self, handle, tag, tensor):
+        return self._timed(tag, tensor.numel() * tensor.element_size(), handle.wait)
+
+    def profile_summary(self, steps):
+        """tag -> {exposed_ms_per_step, calls_per_step, bytes_per_call}; call after a device synchronize."""
+        out = {}
+        for tag, ev in (self.prof or {}).items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in ev)
+            out[tag] = {'exposed_ms_per_step': ms / max(steps, 1), 'calls_per_step': len(ev) / max(steps, 1),
+                        'bytes_per_call': ev[0][2] if ev else 0}
         return out
 
     def label_range(self, L):
@@ -95,8 +132,9 @@ class LabelShard:
             return out, LabelShard._Done()
         return out, dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def all_reduce_(self, t):
-        return self._run(lambda o, i: dist.all_reduce(o, op=dist.ReduceOp.SUM, group=self.group), t, t)
+    def all_reduce_(self, t, tag='all_reduce'):
+        return self._timed(tag, t.numel() * t.element_size(),
+                           lambda: self._run(lambda o, i: dist.all_reduce(o, op=dist.ReduceOp.SUM, group=self.group), t, t))
 
     def all_gather_labels(self, local, L):
         """[B, L_r] column shards (uneven allowed) -> [B, L]."""
@@ -105,7 +143,8 @@ class LabelShard:
         pad = local.new_zeros((width, B))
         pad[:local.shape[1]] = local.t()
         out = local.new_empty((self.world * width, B))
-        self._run(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, pad)
+        self._timed('logits_all_gather', out.numel() * out.element_size(),
+                    lambda: self._run(lambda o, i: dist.all_gather_into_tensor(o, i, group=self.group), out, pad))
         cols = []
         for r in range(self.world):
             b, e = partition(L, self.world, r)

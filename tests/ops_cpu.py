@@ -166,12 +166,16 @@ class CpuOps:
         return torch.from_numpy(rng.attn_dropout_scale(seed, np.arange(B), l_offset + np.arange(L), L_total,
                                                        np.arange(Tp), p))
 
-    def attn_fwd(self, PX, X, Q, l_offset, L_total, seed, p):
+    def attn_fwd(self, PX, X, Q, l_offset, L_total, seed, p, out=None):
         S = torch.einsum('bte,le->blt', PX, Q)
         lse = torch.logsumexp(S, 2)
         P = torch.exp(S - lse[:, :, None])
         d = self._attn_drop(PX.shape[0], Q.shape[0], PX.shape[1], l_offset, L_total, seed, p)
         Pd = P if d is None else P * d
+        if out is not None:
+            out[0].copy_(Pd @ X)
+            out[1].copy_(lse)
+            return out
         return (Pd @ X).contiguous(), lse.contiguous()
 
     def attn_bwd(self, dO, O, PX, X, Q, lse, l_offset, L_total, seed, p, dPX, dX, dQ, nsplit=None):

@@ -25,26 +25,67 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, train, q):
+def _worker(rank, world, port, name, train, mode, q):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        torch.set_num_threads(2)
+        torch.set_num_threads(1 if world > 4 else 2)
         dist.init_process_group('gloo', rank=rank, world_size=world)
         from tests import helpers
         from tests.conftest import load_golden
         from tests.golden import synth
         from tests.ops_cpu import CpuOps
-        g = load_golden(f"{name}_{'train' if train else 'eval'}")
-        case = synth.synth_base(**synth.BASE_CASES[name])
-        model = helpers.build_model(case, ops=CpuOps())
-        model.enable_label_sharding()
-        helpers.check_base_against_golden(model, case, g, train)
+        if mode == 'gan':
+            _gan_variant_sharded(helpers, load_golden, synth, CpuOps())
+        else:
+            g = load_golden(f"{name}_{'train' if train else 'eval'}")
+            case = synth.synth_base(**synth.BASE_CASES[name])
+            model = helpers.build_model(case, ops=CpuOps())
+            model.enable_label_sharding(own_first=(mode == 'own_first'))
+            if mode == 'no_grad':  # forward-only scoring (train_base.py:120-137): no backward, nothing saved
+                model.train() if train else model.eval()
+                model.set_dropout_seed(synth.DROP_SEED)
+                with torch.no_grad():
+                    logits, loss = model(*helpers.batch_tensors(case))
+                assert not logits.requires_grad and not loss.requires_grad
+                helpers.close(logits, g['logits'], 1e-5, 2e-5, 'sharded no_grad logits')
+                helpers.close(loss, g['loss'], 1e-5, 1e-5, 'sharded no_grad loss')
+            else:
+                helpers.check_base_against_golden(model, case, g, train)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, 'ok'))
     except Exception:
         q.put((rank, traceback.format_exc()))
+
+
+def _gan_variant_sharded(helpers, load_golden, synth, ops, device='cpu'):
+    """ConvLabelAttnGAN.forward (full label list and a label subset, finetune.py:242,271) under label sharding against
+    the UNSHARDED golden: logits, loss and the output_fc gradient."""
+    from gzsl_text_amd.modules.icd_modules import ConvLabelAttnGAN
+    g = load_golden('gan_model_tiny')
+    case = synth.synth_base(**synth.BASE_CASES['base_gate_tiny'])
+    model = helpers.build_model(case, cls=ConvLabelAttnGAN, device=device, ops=ops)
+    model.load_pretrained_state_dict({k: torch.from_numpy(v.copy()).to(device) for k, v in case['params'].items()})
+    model.eval()
+    model.init_output_fc(torch.from_numpy(g['fc0']).to(device))
+    model.enable_label_sharding()
+    x, y, mask = helpers.batch_tensors(case, device)
+    model.zero_grad()
+    logits, loss = model(x, y, mask)
+    loss.backward()
+    helpers.close(logits, g['full_logits'], 1e-5, 2e-5, 'sharded GAN-variant logits')
+    helpers.close(loss, g['full_loss'], 1e-5, 1e-5, 'sharded GAN-variant loss')
+    helpers.close(model.output_fc.weight.grad, g['full_dfc'], 1e-4, 1e-6, 'sharded GAN-variant dfc')
+    model.zero_grad()
+    logits, loss = model(x, y, mask, label_indices=torch.from_numpy(g['sub']).to(device))
+    loss.backward()
+    helpers.close(logits, g['sub_logits'], 1e-5, 2e-5, 'sharded subset logits')
+    helpers.close(loss, g['sub_loss'], 1e-5, 1e-5, 'sharded subset loss')
+    helpers.close(model.output_fc.weight.grad, g['sub_dfc'], 1e-4, 1e-6, 'sharded subset dfc')
+    with torch.no_grad():
+        logits, _ = model(x, y, mask)
+    helpers.close(logits, g['full_logits'], 1e-5, 2e-5, 'sharded GAN-variant scoring under no_grad')
 
 
 def run_ranks(target, world, args, timeout=240):
@@ -84,8 +125,8 @@ def run_ranks(target, world, args, timeout=240):
                 p.join(timeout=10)
 
 
-def _run(world, name, train):
-    run_ranks(_worker, world, (name, train))
+def _run(world, name, train, mode='default'):
+    run_ranks(_worker, world, (name, train, mode))
 
 
 @pytest.mark.parametrize('train', [False, True])
@@ -100,6 +141,26 @@ def test_label_sharding_world2_batch_split(train):
 
 def test_label_sharding_world3_uneven_labels():
     _run(3, 'base_gate_tiny', True)  # L = 12 over 3 ranks, B = 3 batch-split, GAN-free base path
+
+
+@pytest.mark.parametrize('world,name', [(2, 'base_gate_medium'), (3, 'base_gate_tiny')])
+def test_label_sharding_own_notes_first_ordering(world, name):
+    _run(world, name, True, mode='own_first')  # own block under the gathers; others first, then own, in backward
+
+
+@pytest.mark.parametrize('mode', ['default', 'own_first'])
+def test_label_sharding_world8(mode):
+    _run(8, 'base_gate_w8', True, mode=mode)  # B = 8, L = 19: one note per rank, label ranges of 3 and 2 rows
+
+
+@pytest.mark.parametrize('world,name,train', [(2, 'base_gate_medium', False), (3, 'base_gate_tiny', True)])
+def test_label_sharding_forward_only_under_no_grad(world, name, train):
+    _run(world, name, train, mode='no_grad')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_label_sharding_gan_variant(world):
+    _run(world, None, False, mode='gan')  # world 2: replicated encoder (B = 3); world 3: batch-split + all-gather
 
 
 def test_partition_covers_range():

@@ -17,7 +17,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gzsl_text_amd.gan_engine import WganGpStep, graphed_step  # noqa: E402
 from gzsl_text_amd.ops_hip import HipOps  # noqa: E402
-from tests.golden import synth  # noqa: E402
+from gzsl_text_amd.utils import synth  # noqa: E402
 
 
 def main():
