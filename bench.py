@@ -153,6 +153,8 @@ def hbm_pass(model, step, timer_ops, d, B, steps=5):
         e1.record()
         delta_ev.append((e0, e1))
     ops_hip.call = call
+    side = os.environ.get('GZSL_NO_SIDE_STREAM')
+    os.environ['GZSL_NO_SIDE_STREAM'] = '1'  # one stream: a kernel's events then bracket that kernel alone
     try:
         t.enabled = True
         for _ in range(steps):
@@ -161,6 +163,10 @@ def hbm_pass(model, step, timer_ops, d, B, steps=5):
         t.enabled = False
     finally:
         ops_hip.call = orig_call
+        if side is None:
+            del os.environ['GZSL_NO_SIDE_STREAM']
+        else:
+            os.environ['GZSL_NO_SIDE_STREAM'] = side
     nnz = int(model._graph_buffers().csr[1].numel())
     by = hbm_bytes(d, B, nnz)
     out = {}

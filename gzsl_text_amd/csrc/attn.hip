@@ -347,6 +347,21 @@ __global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __r
     const int lane = threadIdx.x & 63;
     long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    if ((F & 3) == 0 && (((uintptr_t)dO | (uintptr_t)O) & 15) == 0) {  // 16-byte loads: a lane owns four columns
+        const int F4 = F >> 2;
+        const float4* a4 = reinterpret_cast<const float4*>(dO);
+        const float4* b4 = reinterpret_cast<const float4*>(O);
+        for (; row < rows; row += stride) {
+            float s = 0.f;
+            for (int f = lane; f < F4; f += 64) {
+                const float4 a = a4[row * F4 + f], b = b4[row * F4 + f];
+                s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+            s = wave_sum(s);
+            if (lane == 0) delta[row] = s;
+        }
+        return;
+    }
     for (; row < rows; row += stride) {
         float s = 0.f;
         for (int f = lane; f < F; f += 64) s += dO[row * F + f] * O[row * F + f];

@@ -51,6 +51,27 @@ class GraphBuffers:
         self.csr, self.csr_t = build_csr(adj_matrix)
         self.inv_deg = (1.0 / (num_neighbors.to(torch.float32) + EPS_DEG)).contiguous()
         self.N = self.idx.shape[0]
+        self._desc_inv = {}
+
+    def desc_inverse(self, V, pad_idx=0):
+        """Inverted description index as a CSR over the V embedding rows: row w lists the labels n whose description
+        holds word w, with value mask[n,j] / sum_j mask[n,j] (one entry per occurrence).  The adjoint of
+        average_label_embedding (icd_modules.py:110-113) is then a gather per WORD -- dW[w] += sum val * davg[n] -- instead
+        of 36 M element atomics at cfg2.  One-off setup work (the buffers are registered constants)."""
+        key = (int(V), int(pad_idx))
+        if key not in self._desc_inv:
+            N, Td = self.idx.shape
+            coef = self.cmask / self.cmask.sum(1, keepdim=True)
+            w = self.idx.reshape(-1)
+            n = torch.arange(N, device=w.device).repeat_interleave(Td)
+            keep = (w != pad_idx) & (self.cmask.reshape(-1) != 0)
+            w, n, v = w[keep], n[keep], coef.reshape(-1)[keep]
+            order = torch.argsort(w * N + n, stable=True)
+            w, n, v = w[order], n[order], v[order]
+            rowptr = torch.zeros(V + 1, dtype=torch.int64, device=w.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(w, minlength=V), 0)
+            self._desc_inv[key] = (rowptr.contiguous(), n.contiguous().to(torch.int64), v.contiguous().to(torch.float32))
+        return self._desc_inv[key]
 
 
 class BaseEngine:
@@ -130,7 +151,8 @@ class BaseEngine:
             davg = davg + dx + df
         else:
             davg = davg + dgraph
-        ops.label_avg_bwd_(G['emb.embed.weight'], davg.contiguous(), gb.idx, gb.cmask)
+        ops.label_avg_bwd_(G['emb.embed.weight'], davg.contiguous(), gb.idx, gb.cmask,
+                           inv=gb.desc_inverse(G['emb.embed.weight'].shape[0]))
 
     # ------------------------------------------------------------------------------------------ note encoder
     def encoder_fwd(self, P, x, mask, seed, training, row_offset=0):

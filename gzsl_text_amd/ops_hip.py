@@ -200,8 +200,15 @@ class HipOps:
         call('gzsl_label_avg_fwd', ptr(W), ptr(idx), ptr(mask), ptr(out), N, Td, W.shape[1])
         return out
 
-    def label_avg_bwd_(self, dW, davg, idx, mask, pad_idx=0):
+    def label_avg_bwd_(self, dW, davg, idx, mask, pad_idx=0, inv=None):
+        """dW[idx[n,j]] += mask[n,j] / sum(mask[n]) * davg[n].  inv = GraphBuffers.desc_inverse(V): the same sum as a
+        gather over the inverted index, one float atomic per (word, column)."""
         N, Td = idx.shape
+        if inv is not None:
+            rowptr, col, val = inv
+            call('gzsl_spmm_csr', ptr(rowptr), ptr(col), ptr(val), ptr(davg), None, None, ptr(dW), dW.shape[0],
+                 dW.shape[1], 2)
+            return dW
         call('gzsl_label_avg_bwd', ptr(dW), ptr(davg), ptr(idx), ptr(mask), N, Td, dW.shape[1], pad_idx)
         return dW
 

@@ -90,7 +90,10 @@ int gzsl_label_avg_fwd(const float* W, const int64_t* idx, const float* mask, fl
 int gzsl_label_avg_bwd(float* dW, const float* davg, const int64_t* idx, const float* mask, int N, int Td, int E,
                        int64_t pad_idx, void* stream);
 /* graph_module.py:114-117 (and :70-73): out[n,:] (+)= post[n] * sum_p val[p] * pre[col[p]] * x[col[p],:]  over CSR row n;
- * pre/post may be NULL (=1).  post = 1/(deg+1e-7) gives the neighbour mean; pre with the transposed CSR gives its adjoint. */
+ * pre/post may be NULL (=1).  post = 1/(deg+1e-7) gives the neighbour mean; pre with the transposed CSR gives its adjoint.
+ * accumulate: 0 store, 1 out += (plain), 2 out += with float atomics, empty rows skipped -- the adjoint of
+ * average_label_embedding over the inverted description index (word -> labels), which adds into the word-table gradient
+ * beside the note encoder's scatter-add: one atomic per (word, column) instead of one per (label, slot, column). */
 int gzsl_spmm_csr(const int64_t* rowptr, const int64_t* col, const float* val, const float* x, const float* pre,
                   const float* post, float* out, int N, int H, int accumulate, void* stream);
 /* nn.GRUCell gate math (graph_module.py:122) after the two GEMMs gi = u.Wih^T + bih, gh = h.Whh^T + bhh ([N,3H], r|z|n) */

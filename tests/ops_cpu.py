@@ -106,7 +106,7 @@ class CpuOps:
     def label_avg(self, W, idx, mask):
         return ((W[idx] * mask[:, :, None]).sum(1) / mask.sum(1)[:, None]).contiguous()
 
-    def label_avg_bwd_(self, dW, davg, idx, mask, pad_idx=0):
+    def label_avg_bwd_(self, dW, davg, idx, mask, pad_idx=0, inv=None):
         coef = mask / mask.sum(1, keepdim=True)
         contrib = (coef[:, :, None] * davg[:, None, :]).reshape(-1, davg.shape[1])
         flat = idx.reshape(-1)

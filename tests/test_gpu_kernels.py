@@ -121,8 +121,17 @@ def test_label_avg_bwd_repeated_words(ops, ref):
     idx = torch.from_numpy(np.minimum(rs.zipf(1.4, size=(N, Td)), V - 1).astype(np.int64)) * cm.long()
     davg = rnd(rs, N, E)
     dW = ops.label_avg_bwd_(torch.zeros(V, E, device=DEV), g(davg), g(idx), g(cm))
-    close(dW, ref.label_avg_bwd_(torch.zeros(V, E), davg, idx, cm), 1e-5, 1e-4, 'label avg bwd (repeated words)')
+    want = ref.label_avg_bwd_(torch.zeros(V, E), davg, idx, cm)
+    close(dW, want, 1e-5, 1e-4, 'label avg bwd (repeated words)')
     assert float(dW[0].abs().sum()) == 0.0, 'padding row must get no gradient'
+    # the same adjoint as a gather over the inverted description index (what the engine uses), added on top of a
+    # pre-loaded table with float atomics
+    from gzsl_text_amd.engine import GraphBuffers
+    gb = GraphBuffers(g(idx), g(cm), torch.eye(N).to(DEV).to_sparse(), torch.ones(N, device=DEV))
+    pre = rnd(rs, V, E)
+    dW2 = ops.label_avg_bwd_(g(pre).clone(), g(davg), g(idx), g(cm), inv=gb.desc_inverse(V))
+    close(dW2, pre + want, 1e-5, 1e-4, 'label avg bwd through the inverted index')
+    assert torch.equal(dW2[0].cpu(), pre[0]), 'padding row must get no gradient'
 
 
 @pytest.mark.parametrize('M,N,ld', [(20000, 200, 200), (5000, 37, 64), (300, 100, 100), (9000, 100, 300)])

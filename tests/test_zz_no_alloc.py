@@ -1,8 +1,9 @@
 """Allocation-free entry point (gzsl_colsum_static) against the existing workspace entry point (gzsl_colsum_ws).
 
 Both run the same two kernels over the same row-block partition (the static scratch is never the limiting size at
-these shapes), so the results must be IDENTICAL bit for bit -- a stricter bar than the fp32 tolerance the column sums
-are otherwise held to.  Two calls in a row share the library's per-GPU scratch array: the second, smaller one must not
+these shapes), so wherever the partial sums go through the scratch the results must be IDENTICAL bit for bit -- a
+stricter bar than the fp32 tolerance the column sums are otherwise held to (inputs of <= 8 row blocks take the
+float-atomic path in both entry points and are compared to 1e-5 relative).  Two calls in a row share the library's per-GPU scratch array: the second, smaller one must not
 see anything of the first.  Collected last (test_zz_*): the round-end run uses `pytest -x`.
 """
 import ctypes
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def _both(ops, M, N, ld, seed):
+def _both(ops, M, N, ld, seed, exact=True):
     from gzsl_text_amd import hip
     rs = np.random.RandomState(seed)
     x = torch.from_numpy(rs.standard_normal((M, ld)).astype(np.float32)).to(DEV)[:, :N]
@@ -31,7 +32,10 @@ def _both(ops, M, N, ld, seed):
     assert torch.cuda.memory_stats().get('allocation.all.allocated', 0) == n_alloc_pre  # torch's allocator untouched
     ref = out0.double().cpu() + x.double().cpu().sum(0)
     assert float((got.double().cpu() - ref).abs().max()) <= 2e-5 * np.sqrt(M) + 1e-5 * float(ref.abs().max())
-    assert torch.equal(got, want), float((got - want).abs().max())
+    if exact:
+        assert torch.equal(got, want), float((got - want).abs().max())
+    else:  # <= 8 row blocks: both entry points add their few block sums with float atomics, whose order is not fixed
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
     return got
 
 
@@ -40,7 +44,7 @@ def test_colsum_static_matches_workspace_entry_point_twice_in_a_row():
     ops = HipOps()
     _both(ops, 20000, 200, 200, 1)     # 157 row blocks x 200 columns of partial sums in the scratch array
     _both(ops, 5000, 36, 64, 2)        # smaller, strided, scalar-load path: 40 row blocks; stale partials must not leak
-    _both(ops, 300, 100, 100, 3)       # few rows: the atomic path, scratch unused
+    _both(ops, 300, 100, 100, 3, exact=False)   # few rows: the atomic path, scratch unused
 
 
 def test_colsum_static_rejects_sizes_beyond_its_maximum():
