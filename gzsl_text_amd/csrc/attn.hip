@@ -390,6 +390,12 @@ struct AttnBwdArgs {
     int nsplit;  // label splits per (b, token tile): raises the workgroup count past the CU count
     uint32_t seed, thresh;
     float scale;
+    // deterministic mode (DET kernels): partial sums leave as plain stores into slabs that gzsl_label_attn_bwd_det then
+    // adds up in a fixed order -- dq_slab [B * nTT][L][E] (one slab per (note, token tile)), dpx_slab [nsplit][B][Tp][E],
+    // dx_slab [nsplit][B][Tp][F] (one slab per label split)
+    float* dq_slab;
+    float* dpx_slab;
+    float* dx_slab;
 };
 
 // column of accumulator tile j, lane row/col i, in a block of NT 16-wide tiles read as vectors along the columns:
@@ -448,7 +454,7 @@ __device__ __forceinline__ int img_off(int row, int col, int RS) { return row * 
 // Accumulator tiles hold [token 4*lq + r][column grp_col(j, lr)].  Stage 128 columns at a time as [token][column] in the
 // wave's private LDS rows and add whole token rows to global memory (256 contiguous bytes per wave-instruction: the
 // shape float atomics run at full rate in).  All indices are compile-time after unrolling (no scratch).
-template <int NTILES, int STW, int NARR>
+template <int NTILES, int STW, bool DET, int NARR>
 __device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NARR], float* st, int lane, int tok0, int Tp,
                                            int width, float* out, int ld) {
     const int lr = lane & 15, lq = lane >> 4;
@@ -470,7 +476,10 @@ __device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NARR], float* st
             if (t >= Tp) break;
             for (int c = lane; c < ncol; c += 64) {
                 const int col = 128 * ps + c;
-                if (col < width) atomicAdd(out + (long long)t * ld + col, st[trow * STW + c]);
+                if (col < width) {
+                    if (DET) out[(long long)t * ld + col] = st[trow * STW + c];  // this workgroup's own slab rows
+                    else atomicAdd(out + (long long)t * ld + col, st[trow * STW + c]);
+                }
             }
         }
         wave_lds_fence();  // ... and the next pass overwrites them
@@ -487,7 +496,7 @@ __device__ __forceinline__ void flush_rows(const f32x4 (&tiles)[NARR], float* st
 // DROP: dropout on (compile-time: a runtime test splits the softmax block into one basic block per score element).
 // (Measured and rejected: letting waves 4.. run the previous step's dQ tile product at the START of their step, so that
 // the two waves of a SIMD are not in the same phase at the same time, cost +5.6 % at E = 100 and +7.5 % at E = 200.)
-template <int ES, int NFT, int NW, int G, bool PAIR, bool DROP>
+template <int ES, int NFT, int NW, int G, bool PAIR, bool DROP, bool DET>
 __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kernel(AttnBwdArgs a) {
     using P = BwdLds<ES, NFT, NW, PAIR>;
     constexpr int NWV = P::NWV;
@@ -747,11 +756,16 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
     }
     auto dq_flush = [&](int buf, int l0p) {  // row-contiguous float atomics; fixed trip count, unrolled
         const float* dqo = dQs + buf * BWD_BL * DQW;
-        float* dqg = a.dQ + (long long)l0p * a.E;
+        // DET: every (note, token tile) owns a [L][E] slab and each of its label rows is written by exactly one workgroup
+        float* dqg = (DET ? a.dq_slab + (long long)(b * nTT + tt) * a.L * a.E : a.dQ) + (long long)l0p * a.E;
         const int nrow = a.L - l0p;
 #pragma unroll
-        for (int i = 0; i < DQF; ++i)
-            if (dq_row[i] < nrow) atomicAdd(dqg + dq_goff[i], dqo[tid + NT * i]);
+        for (int i = 0; i < DQF; ++i) {
+            if (dq_row[i] < nrow) {
+                if (DET) dqg[dq_goff[i]] = dqo[tid + NT * i];
+                else atomicAdd(dqg + dq_goff[i], dqo[tid + NT * i]);
+            }
+        }
     };
 
     int l0_p1 = 0, l0_p2 = 0;  // first labels of the previous two steps
@@ -879,7 +893,7 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
                 for (int r = 0; r < 4; ++r) {
                     float p = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
                     float dsc = 1.f;
-                    if (DROP && !(GZ_ABL & 4))
+                    if (DROP && (!DET || a.thresh) && !(GZ_ABL & 4))
                         dsc = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
                     pd[r] = p * dsc;
                     ds[r] = p * ((d0[r] + d1[r]) * dsc - del4[r]);
@@ -952,7 +966,8 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
                 for (int r = 0; r < 4; ++r) {
                     pr[r] = tok_ok ? __expf(s0[r] + s1[r] - lse4[r]) : 0.f;
                     dsc[r] = 1.f;
-                    if (DROP) dsc[r] = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
+                    if (DROP && (!DET || a.thresh))
+                        dsc[r] = (gz_mix32(__float_as_uint(key4[r]) ^ tokmul) >= a.thresh) ? a.scale : 0.f;
                     pdv[r] = pr[r] * dsc[r];
                 }
                 *reinterpret_cast<f32x4*>(xch_pd) = pdv;
@@ -1051,12 +1066,15 @@ __global__ __launch_bounds__((PAIR ? 2 : 1) * NW * 64) void label_attn_bwd_kerne
     // epilogue: dK / dV tiles -> token rows through per-wave LDS staging, row-contiguous atomics
     if (!(GZ_ABL & 16)) {
         float* st = sm + wv * 16 * P::STW;
+        // DET: label split sp owns slab sp; its token rows of note b are written by this workgroup alone
+        float* gk = (DET ? a.dpx_slab + (long long)sp * a.B * a.Tp * a.E : a.dPX) + (long long)b * a.Tp * a.E;
+        float* gv = (DET ? a.dx_slab + (long long)sp * a.B * a.Tp * a.F : a.dX) + (long long)b * a.Tp * a.F;
         if constexpr (!PAIR) {
-            flush_rows<NET, P::STW>(dK, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
-            flush_rows<NFT, P::STW>(dV, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
+            flush_rows<NET, P::STW, DET>(dK, st, lane, tok0, a.Tp, a.E, gk, a.E);
+            flush_rows<NFT, P::STW, DET>(dV, st, lane, tok0, a.Tp, a.F, gv, a.F);
         } else {
-            if (!role_v) flush_rows<NET, P::STW>(acc, st, lane, tok0, a.Tp, a.E, a.dPX + (long long)b * a.Tp * a.E, a.E);
-            else flush_rows<NFT, P::STW>(acc, st, lane, tok0, a.Tp, a.F, a.dX + (long long)b * a.Tp * a.F, a.F);
+            if (!role_v) flush_rows<NET, P::STW, DET>(acc, st, lane, tok0, a.Tp, a.E, gk, a.E);
+            else flush_rows<NFT, P::STW, DET>(acc, st, lane, tok0, a.Tp, a.F, gv, a.F);
         }
     }
 }
@@ -1089,10 +1107,16 @@ static int launch_bwd(const AttnBwdArgs& a, hipStream_t st) {
     const bool vec = (a.E & 3) == 0 && (a.F & 3) == 0 &&
                      (((uintptr_t)a.Q | (uintptr_t)a.dO | (uintptr_t)a.PX | (uintptr_t)a.X) & 15) == 0;
     const size_t smem = (size_t)P::floats * 4;
-    if (vec && a.thresh) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4, PAIR, true>), grid, block, smem, st, a);
-    else if (vec) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 4, PAIR, false>), grid, block, smem, st, a);
-    else if (a.thresh) hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1, PAIR, true>), grid, block, smem, st, a);
-    else hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, 1, PAIR, false>), grid, block, smem, st, a);
+#define GZ_BWD(G_, DROP_, DET_) \
+    hipLaunchKernelGGL((label_attn_bwd_kernel<ES, NFT, NW, G_, PAIR, DROP_, DET_>), grid, block, smem, st, a)
+    if (a.dq_slab) {  // deterministic mode: dropout stays a runtime test there (fewer instantiations; it is not the fast path)
+        if (vec) GZ_BWD(4, true, true);
+        else GZ_BWD(1, true, true);
+    } else if (vec && a.thresh) GZ_BWD(4, true, false);
+    else if (vec) GZ_BWD(4, false, false);
+    else if (a.thresh) GZ_BWD(1, true, false);
+    else GZ_BWD(1, false, false);
+#undef GZ_BWD
     GZSL_CHECK_LAUNCH();
     return 0;
 }
@@ -1139,7 +1163,42 @@ extern "C" int gzsl_label_attn_bwd(const float* dO, const float* PX, const float
     if (Tp <= 0 || E <= 0 || F <= 0 || nsplit <= 0) return GZSL_EINVAL;
     if ((long long)L * F >= (1ll << 31) || (long long)L * E >= (1ll << 31)) return GZSL_EINVAL;  // 32-bit in-note offsets
     AttnBwdArgs a{dO, PX, X, Q, LSE, DELTA, dPX, dX, dQ, B, Tp, E, F, L, l_offset, L_total, nsplit, seed, drop_thresh,
-                  drop_scale};
+                  drop_scale, nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     GZ_DISPATCH(launch_bwd, a, st);
+}
+
+static int bwd_tokens_per_wg(int E) { return E <= 100 ? 128 : 64; }  // launch_bwd's NW * 16
+
+extern "C" long long gzsl_label_attn_bwd_det_work_floats(int B, int Tp, int E, int F, int L, int nsplit) {
+    if (B <= 0 || Tp <= 0 || E <= 0 || F <= 0 || L <= 0 || nsplit <= 0) return 0;
+    const long long nTT = cdiv(Tp, bwd_tokens_per_wg(E));
+    return (long long)B * nTT * L * E + (long long)nsplit * B * Tp * (E + F);
+}
+
+static int launch_bwd_any(const AttnBwdArgs& a, hipStream_t st) { GZ_DISPATCH(launch_bwd, a, st); }
+
+extern "C" int gzsl_label_attn_bwd_det(const float* dO, const float* PX, const float* X, const float* Q, const float* LSE,
+                                       const float* DELTA, float* dPX, float* dX, float* dQ, int B, int Tp, int E, int F,
+                                       int L, int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh,
+                                       float drop_scale, float* work, long long work_floats, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if (Tp <= 0 || E <= 0 || F <= 0 || nsplit <= 0 || !work) return GZSL_EINVAL;
+    if ((long long)L * F >= (1ll << 31) || (long long)L * E >= (1ll << 31)) return GZSL_EINVAL;
+    if (work_floats < gzsl_label_attn_bwd_det_work_floats(B, Tp, E, F, L, nsplit)) return GZSL_EINVAL;
+    const long long nTT = cdiv(Tp, bwd_tokens_per_wg(E));
+    float* dq_slab = work;
+    float* dpx_slab = dq_slab + (long long)B * nTT * L * E;
+    float* dx_slab = dpx_slab + (long long)nsplit * B * Tp * E;
+    AttnBwdArgs a{dO, PX, X, Q, LSE, DELTA, dPX, dX, dQ, B, Tp, E, F, L, l_offset, L_total, nsplit, seed, drop_thresh,
+                  drop_scale, dq_slab, dpx_slab, dx_slab};
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_bwd_any(a, st);
+    if (rc) return rc;
+    // fixed-order sums of the slabs, ADDED to the caller's buffers (same contract as the atomic entry point)
+    rc = gzsl_splitk_reduce(dq_slab, (long long)L * E, (int)(B * nTT), dQ, L, E, E, nullptr, GZSL_ACT_NONE, 1, 0, 0, stream);
+    if (rc) return rc;
+    rc = gzsl_splitk_reduce(dpx_slab, (long long)B * Tp * E, nsplit, dPX, B * Tp, E, E, nullptr, GZSL_ACT_NONE, 1, 0, 0, stream);
+    if (rc) return rc;
+    return gzsl_splitk_reduce(dx_slab, (long long)B * Tp * F, nsplit, dX, B * Tp, F, F, nullptr, GZSL_ACT_NONE, 1, 0, 0, stream);
 }

@@ -688,6 +688,15 @@ __global__ void conv_pack_kernel(const float* __restrict__ W, float* __restrict_
 // -------------------------------------------------------------------------------------------- C ABI
 #define ST ((hipStream_t)stream)
 
+// Library-wide deterministic-reduction switch (include/gzsl_hip.h): reductions that normally end in a few float atomics
+// (whose order is not fixed) take their fixed-order form instead.
+static int g_deterministic = 0;
+extern "C" int gzsl_set_deterministic(int on) {
+    const int prev = g_deterministic;
+    g_deterministic = on ? 1 : 0;
+    return prev;
+}
+
 extern "C" int gzsl_emb_gather_fwd(const float* W, const int64_t* ids, const float* mask, float* out, long long rows,
                                    int E, long long row_offset, uint32_t seed, uint32_t drop_thresh, float drop_scale,
                                    void* stream) {
@@ -755,7 +764,9 @@ extern "C" int gzsl_spmm_csr(const int64_t* rowptr, const int64_t* col, const fl
                              void* stream) {
     if (N <= 0) return 0;
     if (accumulate < 0 || accumulate > 2) return GZSL_EINVAL;
-    if ((H & 3) == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+    // (atomic mode keeps one column per lane: a wave-instruction then adds 256 contiguous bytes, the shape float atomics
+    // run at full rate in; four columns per lane would spread each instruction over 1 KiB in 4-byte pieces)
+    if (accumulate != 2 && (H & 3) == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
         hipLaunchKernelGGL(spmm_csr_v4_kernel, dim3(ew_blocks((long long)N * (H / 4))), dim3(EW_THREADS), 0, ST, rowptr, col,
                            val, x, pre, post, out, N, H / 4, accumulate);
         GZSL_CHECK_LAUNCH();
@@ -882,6 +893,7 @@ extern "C" int gzsl_ldam_bce(const float* logits, const float* y, const float* m
     // 128 blocks are plenty for the <= 1.7 MB this kernel moves (563 blocks cost 20 us at cfg2, 128 cost 6)
     int blocks = ew_blocks((long long)B * L);
     if (blocks > 128) blocks = 128;
+    if (g_deterministic) blocks = 1;  // one block: its waves' sums are added in a fixed order, one add into *loss
     hipLaunchKernelGGL(ldam_bce_kernel, dim3(blocks), dim3(EW_THREADS), 0, ST, logits, y, margin, C, inv_b, loss, dlogits,
                        probs, B, L);
     GZSL_CHECK_LAUNCH();
@@ -925,7 +937,7 @@ static int colsum_launch(const float* x, float* out, long long M, int N, int ld,
         rows_per_block = (int)((M + cap - 1) / cap);
         gy = (M + rows_per_block - 1) / rows_per_block;
     }
-    if (gy <= 8) work = nullptr;  // a handful of atomics per column is cheaper than a second launch
+    if (gy <= 8 && !g_deterministic) work = nullptr;  // a handful of atomics per column is cheaper than a second launch
     if ((N & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0)
         hipLaunchKernelGGL(colsum_kernel<4>, dim3(cdiv(N, 256), (unsigned)gy), dim3(256), 0, st, x, out, work, M, N, ld,
                            rows_per_block);

@@ -38,6 +38,9 @@ _PROTOS = {
     'gzsl_label_attn_fwd': [c_void_p] * 5 + [c_int] * 7 + [c_u32, c_u32, c_float, c_void_p],
     'gzsl_attn_delta': [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p],
     'gzsl_label_attn_bwd': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p],
+    'gzsl_label_attn_bwd_det': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p, c_ll, c_void_p],
+    'gzsl_label_attn_bwd_det_work_floats': [c_int] * 6,
+    'gzsl_set_deterministic': [c_int],
     'gzsl_emb_gather_fwd': [c_void_p] * 4 + [c_ll, c_int, c_ll, c_u32, c_u32, c_float, c_void_p],
     'gzsl_emb_scatter_add': [c_void_p] * 4 + [c_ll, c_int, c_ll, c_ll, c_u32, c_u32, c_float, c_void_p],
     'gzsl_emb_scatter_add_grouped': [c_void_p] * 4 + [c_ll, c_int, c_ll, c_ll, c_u32, c_u32, c_float, c_void_p],
@@ -89,7 +92,7 @@ def load():
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_ll if name == 'gzsl_label_attn_bwd_det_work_floats' else c_int
     lib.gzsl_build_info.restype = ctypes.c_char_p
     lib.gzsl_build_info.argtypes = []
     _lib = lib

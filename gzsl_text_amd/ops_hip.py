@@ -27,7 +27,19 @@ def _check_f32(*ts):
 
 
 class HipOps:
+    """deterministic=True (or GZSL_DETERMINISTIC=1): every cross-workgroup sum of the train step takes a fixed-order
+    form -- attention gradients through slabs + ordered reduce (gzsl_label_attn_bwd_det), the embedding gradient as a
+    gather over a sorted index instead of float atomics, loss / column sums without atomics, one stream.  Two runs on
+    the same inputs are then bit-identical (tests/test_gpu_model.py); it costs memory and ~10 % of the step."""
     name = 'hip'
+
+    def __init__(self, deterministic=None):
+        import os
+        self.deterministic = (os.environ.get('GZSL_DETERMINISTIC') == '1') if deterministic is None else bool(deterministic)
+        if self.deterministic:
+            from .streams import Beside
+            Beside.serial = True
+            hip.load().gzsl_set_deterministic(1)
 
     # ------------------------------------------------------------------------------------ GEMM plumbing
     @staticmethod
@@ -98,7 +110,7 @@ class HipOps:
         assert x2d.stride(1) == 1
         if out is None:
             out = torch.zeros(N, dtype=torch.float32, device=x2d.device)
-        if M >= 4096:  # partial sums through a workspace instead of thousands of same-address atomics
+        if M >= 4096 or self.deterministic:  # partial sums through a workspace instead of thousands of same-address atomics
             work = torch.empty(min(512, (M + 127) // 128) * N, dtype=torch.float32, device=x2d.device)
             call('gzsl_colsum_ws', dptr(x2d), ptr(out), M, N, x2d.stride(0), ptr(work), work.numel())
         else:
@@ -128,6 +140,21 @@ class HipOps:
     def emb_scatter_add_(self, dW, ids, mask, dOut, seed, p, pad_idx=0, row_offset=0):
         th, sc = drop_params(p)
         rows, E = ids.numel(), dW.shape[1]
+        if self.deterministic:
+            # fixed order: apply mask x dropout to the rows (emb_gather over the identity index computes exactly that),
+            # then gather per WORD over the token rows sorted by (id, row) -- no atomics
+            flat = ids.reshape(-1)
+            g = self.emb_gather(dOut.reshape(rows, E), torch.arange(rows, device=flat.device), mask, seed, p, row_offset)
+            keep = flat != pad_idx
+            r = torch.arange(rows, device=flat.device)[keep]
+            w = flat[keep]
+            order = torch.argsort(w * rows + r, stable=True)
+            w, r = w[order], r[order]
+            rowptr = torch.zeros(dW.shape[0] + 1, dtype=torch.int64, device=flat.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(w, minlength=dW.shape[0]), 0)
+            self.spmm((rowptr, r.contiguous(), torch.ones(r.numel(), dtype=torch.float32, device=flat.device)),
+                      g.view(rows, E), out=dW, accumulate=True)
+            return dW
         # many rows per id (word ids are Zipf-distributed): sum runs of equal ids inside 128-row chunks first
         name = 'gzsl_emb_scatter_add_grouped' if (rows >= 1024 and E <= 297) else 'gzsl_emb_scatter_add'
         call(name, ptr(dW), ptr(ids), ptr(mask), ptr(dOut), rows, E, pad_idx, row_offset, seed & 0xFFFFFFFF, th, sc)
@@ -207,14 +234,14 @@ class HipOps:
         if inv is not None:
             rowptr, col, val = inv
             call('gzsl_spmm_csr', ptr(rowptr), ptr(col), ptr(val), ptr(davg), None, None, ptr(dW), dW.shape[0],
-                 dW.shape[1], 2)
+                 dW.shape[1], 1 if self.deterministic else 2)
             return dW
         call('gzsl_label_avg_bwd', ptr(dW), ptr(davg), ptr(idx), ptr(mask), N, Td, dW.shape[1], pad_idx)
         return dW
 
     def spmm(self, csr, x, pre=None, post=None, out=None, accumulate=False):
         rowptr, col, val = csr
-        N, H = x.shape
+        N, H = rowptr.numel() - 1, x.shape[1]   # output rows = CSR rows (x may have a different row count)
         if out is None:
             assert not accumulate
             out = torch.empty((N, H), dtype=torch.float32, device=x.device)
@@ -275,6 +302,13 @@ class HipOps:
         """The label_attn_bwd kernel alone (bench.py times this launch for the roofline line)."""
         B, Tp, E = PX.shape
         th, sc = drop_params(p)
+        if self.deterministic:
+            n = hip.load().gzsl_label_attn_bwd_det_work_floats(B, Tp, E, X.shape[2], Q.shape[0], nsplit)
+            work = torch.empty(n, dtype=torch.float32, device=PX.device)
+            call('gzsl_label_attn_bwd_det', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
+                 ptr(dQ), B, Tp, E, X.shape[2], Q.shape[0], l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc,
+                 ptr(work), n)
+            return
         call('gzsl_label_attn_bwd', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
              ptr(dQ), B, Tp, E, X.shape[2], Q.shape[0], l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc)
 

@@ -14,9 +14,12 @@ class Beside:
     stream at `join()` (so everything produced there is visible, and later frees are ordered after its readers)."""
 
     _streams = {}
+    serial = False  # set by HipOps(deterministic=True)
 
     def __init__(self, ref_tensor):
-        self.on = ref_tensor.is_cuda and os.environ.get('GZSL_NO_SIDE_STREAM') != '1'
+        # (deterministic mode: both branches add into the word-table gradient -- one stream fixes their order)
+        self.on = (ref_tensor.is_cuda and os.environ.get('GZSL_NO_SIDE_STREAM') != '1'
+                   and os.environ.get('GZSL_DETERMINISTIC') != '1' and not Beside.serial)
         if self.on:
             dev = ref_tensor.device
             self.main = torch.cuda.current_stream(dev)

@@ -70,6 +70,21 @@ int gzsl_label_attn_bwd(const float* dO, const float* PX, const float* X, const 
                         int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh, float drop_scale,
                         void* stream);
 
+/* Deterministic form of gzsl_label_attn_bwd (SURVEY 5 asks for a deterministic-reduction mode; the reference itself is
+ * only as reproducible as torch's atomics-based embedding / index_add backward): the partial sums leave as plain stores
+ * into `work` -- one [L,E] slab of dQ per (note, token tile), one [B,Tp,E] / [B,Tp,F] slab of dPX / dX per label split --
+ * and are then ADDED to dPX / dX / dQ in a fixed order.  Same arguments and result (up to summation order) as the
+ * atomic entry point; two calls on the same inputs give bit-identical outputs.  work_floats must be at least
+ * gzsl_label_attn_bwd_det_work_floats(...) (1.3 GB at cfg2: a mode, not the fast path). */
+long long gzsl_label_attn_bwd_det_work_floats(int B, int Tp, int E, int F, int L, int nsplit);
+int gzsl_label_attn_bwd_det(const float* dO, const float* PX, const float* X, const float* Q, const float* LSE,
+                            const float* DELTA, float* dPX, float* dX, float* dQ, int B, int Tp, int E, int F, int L,
+                            int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh, float drop_scale,
+                            float* work, long long work_floats, void* stream);
+/* Library-wide switch for the small reductions that otherwise end in a handful of float atomics (gzsl_ldam_bce's loss:
+ * one block; gzsl_colsum_ws: always through the workspace).  Returns the previous setting.  Not a stream operation. */
+int gzsl_set_deterministic(int on);
+
 /* ---- embedding / label side -------------------------------------------------------------------------------------
  * out[row,:] = W[ids[row],:] * mask[row] * dropout;  common_module.py:87-88 + icd_modules.py:153-157 (mask may be NULL).
  * row_offset = global index of row 0 (b0*T when a rank encodes notes b0.. of the batch): the dropout hash is keyed on it. */

@@ -103,6 +103,35 @@ def test_label_gru_hip_matches_reference_golden():
     close(got, want, 1e-4, 1e-5, 'HIP packed GRU vs torch GRU (E=200, 300 ragged descriptions)')
 
 
+@pytest.mark.parametrize('name', ['base_gate_medium', 'base_gate_e200'])
+def test_deterministic_mode_is_bit_reproducible(name):
+    """HipOps(deterministic=True): attention gradients through slabs + an ordered reduce, the embedding gradient as a
+    gather over a sorted index, loss / column sums without atomics, one stream.  Two train steps on the same inputs must
+    agree bit for bit in loss, logits and every gradient -- and still match the reference's golden vectors."""
+    from gzsl_text_amd import hip
+    from gzsl_text_amd.ops_hip import HipOps
+    from gzsl_text_amd.streams import Beside
+    g = load_golden(f'{name}_train')
+    case = synth.synth_base(**synth.BASE_CASES[name])
+    try:
+        model = helpers.build_model(case, device=DEV, ops=HipOps(deterministic=True))
+        helpers.check_base_against_golden(model, case, g, True, device=DEV, grad_atol=4e-6)
+        x, y, mask = helpers.batch_tensors(case, DEV)
+        runs = []
+        for _ in range(2):
+            model.train()
+            model.set_dropout_seed(synth.DROP_SEED)
+            model.zero_grad()
+            logits, loss = model(x, y, mask)
+            loss.mean().backward()
+            runs.append([logits.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in model.parameters()])
+        for a, b in zip(*runs):
+            assert torch.equal(a, b), float((a - b).abs().max())
+    finally:
+        hip.load().gzsl_set_deterministic(0)
+        Beside.serial = False
+
+
 def test_gan_step_replayed_as_hip_graph_matches_eager():
     """The whole WGAN-GP step (critic iterations + generator iteration + Adam) records into one HIP graph: nothing in
     the C ABI allocates or synchronises.  One eager step plus three replays must land on the parameters four eager steps reach."""
