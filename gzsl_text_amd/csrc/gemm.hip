@@ -417,6 +417,116 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
     }
 }
 
+// ---- skinny GEMM: M <= 32 rows (the WGAN-GP step at the drivers' default batch of 8, train_gan.py:223-308) --------------
+// The tiled kernel above gives such a product to a handful of workgroups that each walk all of K behind one barrier per
+// 16 k (25-40 us for 8 x 800 x 800).  Here every workgroup owns 16 output columns, its four waves split K between
+// them, and the operands go straight from global memory into MFMA fragments (a lane's 16-byte load = its k values of
+// four consecutive steps: k = 16*group + 4*quarter + step, the same free choice of k order as everywhere else) -- no
+// LDS staging, no barrier in the loop; the four partial tiles meet in LDS once at the end.
+template <int MT, bool BKC, bool VEC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GzslGemm g) {
+    __shared__ float red[4][MT][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int n = n0 + lr;
+    const bool n_ok = n < g.N;
+    const float* bp = g.B + (long long)min(n, g.N - 1) * g.b_sn;
+    const float* arow[MT];
+    bool a_ok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = 16 * t + lr;
+        a_ok[t] = m < g.M;
+        arow[t] = g.A + (long long)min(m, g.M - 1) * g.a_sm;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = (g.K + 15) / 16;
+#pragma unroll 4
+    for (int gi = wave; gi < ngroups; gi += 4) {
+        const int k0 = 16 * gi + 4 * lq;
+        float a[MT][4], b[4];
+        if (VEC) {  // K % 4 == 0: the lane's four k are all inside K or all outside
+            const bool k_ok = k0 < g.K;
+            const int kc = k_ok ? k0 : 0;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(arow[t] + kc);
+                const float keep = (a_ok[t] && k_ok) ? 1.f : 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[t][s] = v[s] * keep;
+            }
+            const float keepb = (n_ok && k_ok) ? 1.f : 0.f;
+            if (BKC) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bp + kc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[s] = v[s] * keepb;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[s] = bp[(long long)(kc + s) * g.b_sk] * keepb;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool k_ok = k0 + s < g.K;
+                const int kc = k_ok ? k0 + s : 0;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a[t][s] = arow[t][(long long)kc * g.a_sk] * ((a_ok[t] && k_ok) ? 1.f : 0.f);
+                b[s] = bp[(long long)kc * g.b_sk] * ((n_ok && k_ok) ? 1.f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = mfma16(a[t][s], b[s], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][lane * 4 + r] = acc[t][r];
+    __syncthreads();
+    // thread tid finishes accumulator element (lane' = tid >> 2, r = tid & 3) of every row tile: row 4*(lane' >> 4) + r,
+    // column lane' & 15; the four waves' partial sums are added in a fixed order
+    const int ln = tid >> 2, r = tid & 3;
+    const int col = n0 + (ln & 15);
+    if (col >= g.N) return;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int row = 16 * t + 4 * (ln >> 4) + r;
+        if (row >= g.M) continue;
+        float v = g.alpha * (red[0][t][tid] + red[1][t][tid] + red[2][t][tid] + red[3][t][tid]) + bv;
+        float* cp = g.C + (long long)row * g.ldc + col;
+        if (g.accumulate) v += *cp;
+        if (g.act == GZSL_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (g.act == GZSL_ACT_TANH) v = tanhf(v);
+        else if (g.act == GZSL_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        *cp = v;
+    }
+}
+
+static int launch_skinny(const GzslGemm& g, hipStream_t st) {
+    const bool bkc = g.b_sk == 1;
+    const bool vec = g.a_sk == 1 && (g.K & 3) == 0 && (g.a_sm & 3) == 0 && ((uintptr_t)g.A & 15) == 0 &&
+                     (!bkc || ((g.b_sn & 3) == 0 && ((uintptr_t)g.B & 15) == 0));
+    const dim3 grid(cdiv(g.N, 16)), block(256);
+#define GZ_SK(MT, KC, V) hipLaunchKernelGGL((gemm_skinny_kernel<MT, KC, V>), grid, block, 0, st, g)
+#define GZ_SK2(MT)                             \
+    do {                                       \
+        if (bkc && vec) GZ_SK(MT, true, true); \
+        else if (vec) GZ_SK(MT, false, true);  \
+        else if (bkc) GZ_SK(MT, true, false);  \
+        else GZ_SK(MT, false, false);          \
+    } while (0)
+    if (g.M <= 16) GZ_SK2(1);
+    else GZ_SK2(2);
+#undef GZ_SK2
+#undef GZ_SK
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
 // out[m*ldo + n] (=|+=) act(sum_z slab[z*stride + m*N + n] + bias[n]);  optional conv-weight unpack:
 // when unpack_k > 0 the slab holds dWp^T as [(j*E + e), f] and out is the reference layout [F, E, k]
 // (conv_modules.0.weight, icd_modules.py:74): out[f][e][j] = sum_z slab[(j*E+e)*F + f].
@@ -527,6 +637,11 @@ extern "C" int gzsl_gemm(const GzslGemm* gp, void* stream) {
         if (g.k_per_split <= 0 || g.k_per_split % BK != 0) return GZSL_EINVAL;
         if ((long long)g.k_per_split * g.split_k < g.K) return GZSL_EINVAL;
     }
+    // few rows, plain operands: the skinny kernel (columns over workgroups, K over the waves of a workgroup)
+    static const int no_skinny = env_int("GZSL_GEMM_NO_SKINNY", 0);
+    if (!no_skinny && g.M <= 32 && g.K >= 32 && g.split_k <= 1 && g.a_mb >= g.M && g.k_inner >= g.K && g.a_shift == 0 &&
+        g.a_span >= 0x7FFFFFFFu)
+        return launch_skinny(g, st);
     // tile width: the one whose padded N wastes least MFMA work (ties -> wider tile) ...
     const int pad128 = cdiv(g.N, 128) * 128, pad208 = cdiv(g.N, 208) * 208, pad112 = cdiv(g.N, 112) * 112;
     int wn = (pad208 < pad128 && pad208 <= pad112) ? 13 : (pad112 < pad128 ? 7 : 8);

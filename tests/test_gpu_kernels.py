@@ -52,6 +52,28 @@ def test_gemm_all_layouts(ops, ref, M, N, K, ta, tb):
     close(out, ref.mm(A, B, out=C0.clone(), accumulate=True, alpha=0.5), 2e-5, 2e-5 * np.sqrt(K), 'mm accumulate')
 
 
+@pytest.mark.parametrize('M', [1, 8, 16, 17, 32])
+@pytest.mark.parametrize('N,K', [(800, 800), (400, 800), (1, 64), (100, 333), (4096, 200), (37, 32)])
+def test_gemm_skinny_rows(ops, ref, M, N, K):
+    """M <= 32 takes the skinny kernel (gemm.hip): every operand layout the WGAN-GP step feeds it (x @ W^T, x @ W,
+    column blocks of W with an offset base, strided activations), bias / activation / accumulate / alpha."""
+    rs = np.random.RandomState(M * 131 + N + K)
+    x, W, Wt, bias = rnd(rs, M, K), rnd(rs, N, K, scale=0.1), rnd(rs, K, N, scale=0.1), rnd(rs, N)
+    for act in (0, 1, 2, 3):
+        close(ops.mm(g(x), g(W).t(), bias=g(bias), act=act), ref.mm(x, W.t(), bias=bias, act=act), 2e-5, 2e-5 * np.sqrt(K),
+              f'x @ W^T act={act}')
+    close(ops.mm(g(x), g(Wt)), x @ Wt, 2e-5, 2e-5 * np.sqrt(K), 'x @ W (row-contiguous B)')
+    C0 = rnd(rs, M, N)
+    close(ops.mm(g(x), g(W).t(), out=g(C0).clone(), accumulate=True, alpha=0.5), C0 + 0.5 * (x @ W.t()), 2e-5,
+          2e-5 * np.sqrt(K), 'accumulate + alpha')
+    if K >= 64:  # two K segments of one weight (torch.cat folded into two GEMMs, gan_engine.py) and a strided A
+        k1 = (K // 2) // 4 * 4 + (0 if K % 4 == 0 else 1)
+        out = ops.mm(g(x)[:, :k1], g(W)[:, :k1].t(), bias=g(bias))
+        ops.mm(g(x)[:, k1:], g(W)[:, k1:].t(), out=out, accumulate=True, act=3)
+        want = torch.nn.functional.leaky_relu(x @ W.t() + bias, 0.2)
+        close(out, want, 2e-5, 2e-5 * np.sqrt(K), 'two K segments with LeakyReLU')
+
+
 def test_gemm_split_k_and_strided_output(ops, ref):
     rs = np.random.RandomState(5)
     M, N, K = 100, 200, 20000

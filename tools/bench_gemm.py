@@ -73,6 +73,15 @@ def main():
     add('gru fwd       12000x300x100  KC/KC', 2.0 * N * 3 * H * H, lambda: ops.linear(hN, Wih))
     add('gru dgrad     12000x100x300  KC/RC', 2.0 * N * 3 * H * H, lambda: ops.mm(dg, Wih))
     add('gru wgrad     300x100x12000  RC/RC', 2.0 * N * 3 * H * H, lambda: ops.mm(dg.t(), hN))
+    if os.environ.get('GZ_TORCH_MM') == '1':  # what the vendor library (rocBLAS / hipBLASLt through torch.mm) does on the same shapes
+        add('torch.mm outproj fwd  144000x200x200', 2.0 * B * L * F * D, lambda: torch.mm(O, Wo.t()))
+        add('torch.mm outproj dgrad', 2.0 * B * L * F * D, lambda: torch.mm(dDir, Wo))
+        add('torch.mm outproj wgrad 200x200x144000', 2.0 * B * L * F * D, lambda: torch.mm(dDir.t(), O))
+        A = rnd(M1, E * k)
+        add('torch.mm conv-shaped 39856x200x1000', 2.0 * M1 * F * E * k, lambda: torch.mm(A, Wc.view(F, E * k).t()))
+        add('torch.mm conv wgrad-shaped 1000x200x39856', 2.0 * M1 * F * E * k, lambda: torch.mm(A.t(), X.view(M1, F)))
+        add('torch.mm proj 39856x100x200', 2.0 * M1 * E * F, lambda: torch.mm(X.view(M1, F), Wp.t()))
+        add('torch.mm proj dgrad 39856x200x100', 2.0 * M1 * E * F, lambda: torch.mm(dPX, Wp))
     per_step = (rows[0][1] + rows[1][1] + rows[2][1] + rows[3][1] + rows[4][1] + rows[5][1] + rows[6][1] + rows[7][1]
                 + 4 * (rows[8][1] + rows[9][1] + rows[10][1]))
     print(f'GEMM family per training step ~ {per_step:.3f} ms')
