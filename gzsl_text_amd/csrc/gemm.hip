@@ -323,18 +323,53 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
 #pragma unroll
         for (int kg = 0; kg < BK / 16; ++kg) {
             if (kg > 0 && kbeg + t * BK + 16 * kg >= kend) break;  // K tail: nothing but zeros in this k group
-            float fa[WTM][4], fb[WTN][4];
+            float fa[WTM][4];
             read_frags<WTM, 4 * WTM, BM, A_RC>(abuf, kg, wave * WTM, lr, lq, fa);
-            read_frags<WTN, WTN, BNP, B_RC>(abuf + ASZ, kg, 0, lr, lq, fb);
-            if (!(GZ_GEMM_ABL & 8)) {
+            if constexpr (!B_RC && WTN > 8 && !(GZ_GEMM_ABL & 8)) {
+                // [row][k] image of a wide B tile: its fragments are read and consumed in two halves.  All 13 x 4 at once
+                // put the kernel over the 168 registers three workgroups per CU allow, and the spill reloads sat inside
+                // this loop -- behind a vmcnt wait that also waited for the tile loads issued at the top of the iteration
+                // (the whole global-load latency exposed, every k-tile).
+                constexpr int H0 = (WTN + 1) / 2, H1 = WTN - H0;
+                const float* bb = abuf + ASZ;
+                float fb0[H0][4], fb1[H1][4];
+#pragma unroll
+                for (int i = 0; i < H0; ++i) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(bb + kc_off(16 * i + lr, 4 * kg + lq));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb0[i][j] = t[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                        for (int n = 0; n < WTN; ++n) acc[i][n] = mfma16(fa[i][j], fb[n][j], acc[i][n]);
+                        for (int n = 0; n < H0; ++n) acc[i][n] = mfma16(fa[i][j], fb0[n][j], acc[i][n]);
+#pragma unroll
+                for (int i = 0; i < H1; ++i) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(bb + kc_off(16 * (H0 + i) + lr, 4 * kg + lq));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb1[i][j] = t[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                        for (int n = 0; n < H1; ++n) acc[i][H0 + n] = mfma16(fa[i][j], fb1[n][j], acc[i][H0 + n]);
             } else {
-                acc[0][0][0] += fa[0][0] + fb[0][0];
+                float fb[WTN][4];
+                read_frags<WTN, WTN, BNP, B_RC>(abuf + ASZ, kg, 0, lr, lq, fb);
+                if (!(GZ_GEMM_ABL & 8)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                            for (int n = 0; n < WTN; ++n) acc[i][n] = mfma16(fa[i][j], fb[n][j], acc[i][n]);
+                } else {
+                    acc[0][0][0] += fa[0][0] + fb[0][0];
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // ... and nothing waits on them until the MFMAs have issued
