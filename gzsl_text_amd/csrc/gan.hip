@@ -20,6 +20,8 @@ static inline int ew_blocks(long long n, int per = 256) {
     return (int)b;
 }
 
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 __global__ void gp_interp_kernel(const float* __restrict__ real, const float* __restrict__ fake,
                                  const float* __restrict__ alpha, float* __restrict__ out, int Bg, int D) {
     const long long n = (long long)Bg * D;
@@ -39,37 +41,51 @@ __global__ void gp_slope_v_kernel(const float* __restrict__ h, const float* __re
     }
 }
 
-__global__ void gp_rownorm_kernel(float* __restrict__ g, float* gp, int Bg, int D, float lam) {
+// One wave per row; with V = 4 (D % 4 == 0, 16-byte aligned rows) a row of D <= 1024 floats stays in registers between
+// the norm and the scaling pass (one read, one write).
+template <int V>
+__global__ __launch_bounds__(256) void gp_rownorm_kernel(float* __restrict__ g, float* gp, int Bg, int D, float lam) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int row = blockIdx.x * (blockDim.x >> 6) + wv;
+    int row = blockIdx.x * 4 + wv;
     float part = 0.f;  // this wave's share of the penalty: one atomic per block (same-address atomics cost ~100 ns each)
-    for (; row < Bg; row += gridDim.x * (blockDim.x >> 6)) {
+    for (; row < Bg; row += gridDim.x * 4) {
+        float* gr = g + (long long)row * D;
         float ss = 0.f;
-        for (int d = lane; d < D; d += 64) {
-            const float x = g[(long long)row * D + d];
-            ss += x * x;
+        f32x4 keep[4];
+        if (V == 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d = (lane + 64 * u) * 4;
+                keep[u] = d < D ? *reinterpret_cast<const f32x4*>(gr + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ss += keep[u][0] * keep[u][0] + keep[u][1] * keep[u][1] + keep[u][2] * keep[u][2] + keep[u][3] * keep[u][3];
+            }
+            for (int d = (lane + 256) * 4; d < D; d += 256)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ss += gr[d + k] * gr[d + k];
+        } else {
+            for (int d = lane; d < D; d += 64) ss += gr[d] * gr[d];
         }
         ss = wave_sum(ss);
         const float nrm = sqrtf(ss);
         const float coef = nrm > 0.f ? lam * 2.f * (nrm - 1.f) / ((float)Bg * nrm) : 0.f;
-        for (int d = lane; d < D; d += 64) g[(long long)row * D + d] *= coef;
+        if (V == 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d = (lane + 64 * u) * 4;
+                if (d < D) *reinterpret_cast<f32x4*>(gr + d) = keep[u] * coef;
+            }
+            for (int d = (lane + 256) * 4; d < D; d += 256)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gr[d + k] *= coef;
+        } else {
+            for (int d = lane; d < D; d += 64) gr[d] *= coef;
+        }
         part += lam * (nrm - 1.f) * (nrm - 1.f) / (float)Bg;
     }
     if (lane == 0) red[wv] = part;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(gp, red[0] + red[1] + red[2] + red[3]);
-}
-
-__global__ void gp_dw2_kernel(const float* __restrict__ dv, const float* __restrict__ s, float* dw2, int Bg, int H,
-                              int rows_per_block) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= H) return;
-    const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = min(Bg, r0 + rows_per_block);
-    float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += dv[(long long)r * H + col] * s[(long long)r * H + col];
-    atomicAdd(dw2 + col, acc);
 }
 
 // lrelu_in: `a` holds PRE-activations; LeakyReLU(0.2) is applied on the fly (the activated tensor is never stored)
@@ -121,17 +137,31 @@ __global__ void rowdot_bwd_kernel(const float* __restrict__ dout, const float* _
     }
 }
 
-// One workgroup per row: log-softmax over Vk in three sweeps (max, sum, write) with the row kept in L1/L2.
-__global__ void keyword_ce_kernel(float* __restrict__ logits, const int64_t* __restrict__ kw_idx,
-                                  const float* __restrict__ kw_mask, const float* __restrict__ w,
-                                  float* __restrict__ loss_b, int Bg, int Vk, int top_k) {
+// One workgroup per row: log-softmax over Vk.  REG (Vk % 4 == 0, Vk <= 8192, aligned rows): the row is read once into
+// registers (8 float4 per lane) and written once; otherwise three sweeps (max, sum, write) with the row kept in L1/L2.
+template <bool REG>
+__global__ __launch_bounds__(256) void keyword_ce_kernel(float* __restrict__ logits, const int64_t* __restrict__ kw_idx,
+                                                         const float* __restrict__ kw_mask, const float* __restrict__ w,
+                                                         float* __restrict__ loss_b, int Bg, int Vk, int top_k,
+                                                         int sim_mode, float grad_scale, float loss_scale, float* loss_sum) {
     __shared__ float red[4];
     __shared__ float bcast;
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float* lg = logits + (long long)row * Vk;
+    const int n4 = Vk >> 2;
+    f32x4 x[8];
     float mx = -INFINITY;
-    for (int v = tid; v < Vk; v += blockDim.x) mx = fmaxf(mx, lg[v]);
+    if (REG) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u;
+            x[u] = i < n4 ? reinterpret_cast<const f32x4*>(lg)[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            mx = fmaxf(fmaxf(mx, fmaxf(x[u][0], x[u][1])), fmaxf(x[u][2], x[u][3]));
+        }
+    } else {
+        for (int v = tid; v < Vk; v += blockDim.x) mx = fmaxf(mx, lg[v]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if (lane == 0) red[wv] = mx;
@@ -139,7 +169,17 @@ __global__ void keyword_ce_kernel(float* __restrict__ logits, const int64_t* __r
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float se = 0.f;
-    for (int v = tid; v < Vk; v += blockDim.x) se += expf(lg[v] - mx);
+    if (REG) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                x[u][k] = expf(x[u][k] - mx);  // exp(-inf) = 0 in the padding slots
+                se += x[u][k];
+            }
+    } else {
+        for (int v = tid; v < Vk; v += blockDim.x) se += expf(lg[v] - mx);
+    }
     se = wave_sum(se);
     if (lane == 0) red[wv] = se;
     __syncthreads();
@@ -164,10 +204,26 @@ __global__ void keyword_ce_kernel(float* __restrict__ logits, const int64_t* __r
         loss_b[row] = lsum;
         bcast = tsum;
     }
-    __syncthreads();
+    __syncthreads();  // thread 0 has read its lg[id] before anybody overwrites the row
     tsum = bcast;
-    const float wb = w ? w[row] : 1.f;
-    for (int v = tid; v < Vk; v += blockDim.x) lg[v] = wb * expf(lg[v] - lse) * tsum;
+    // sim_mode (train_gan.py:288-296): keywords_weight = sim.masked_fill(sim != 1, 0); the row's gradient weight is
+    // keywords_weight * grad_scale and *loss_sum += loss_b * keywords_weight * loss_scale
+    float wb = w ? w[row] : 1.f;
+    if (sim_mode) {
+        const float kww = (w && w[row] != 1.f) ? 0.f : 1.f;
+        wb = kww * grad_scale;
+        if (tid == 0 && loss_sum) atomicAdd(loss_sum, lsum * kww * loss_scale);
+    }
+    if (REG) {
+        const float sc = wb * tsum / se;  // softmax = exp(x - mx) / se
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + 256 * u;
+            if (i < n4) reinterpret_cast<f32x4*>(lg)[i] = x[u] * sc;
+        }
+    } else {
+        for (int v = tid; v < Vk; v += blockDim.x) lg[v] = wb * expf(lg[v] - lse) * tsum;
+    }
     __syncthreads();
     if (tid == 0) {
         for (int j = 0; j < top_k; ++j) {
@@ -177,6 +233,269 @@ __global__ void keyword_ce_kernel(float* __restrict__ logits, const int64_t* __r
             if (live) lg[id] -= wb * kw_mask[(long long)row * top_k + j] * inv;
         }
     }
+}
+
+// ---- whole-iteration kernels of the WGAN-GP step engine (gzsl_text_amd/gan_engine.py) --------------------------------
+// A lane owns V adjacent hidden columns and walks the rows of its row block (rows interleaved over the block's four
+// waves), so the per-column sums (d fc2.weight) stay in registers until one atomic per column and row block; everything
+// per-row-and-column is a pure map.  V = 4 when H % 4 == 0 and the buffers are 16-byte aligned.
+template <int V>
+struct VecF {
+    float v[V];
+};
+template <int V>
+__device__ __forceinline__ VecF<V> ldv(const float* p) {
+    VecF<V> r;
+    if (V == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r.v[i] = t[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) r.v[i] = p[i];
+    }
+    return r;
+}
+template <int V>
+__device__ __forceinline__ void stv(float* p, const VecF<V>& r) {
+    if (V == 4) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{r.v[0], r.v[1 % V], r.v[2 % V], r.v[3 % V]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) p[i] = r.v[i];
+    }
+}
+
+#define HEAD_RB 16  // rows per row block
+
+// Critic iteration, everything between the fc1 GEMMs and the gradient GEMMs (train_gan.py:244-256 +
+// generative_module.py:22-38, closed form):
+//   hf [2Bg,H] = [real; fake] @ W1[:, :D]^T,  lh [Bg,H] = lab @ W1[:, D:]^T + b1   (pre-activations h = hf + lh)
+//   wb = sim_b / Bg (1 / Bg without sim);  s(x) = LeakyReLU'(x) in {1, 0.2}
+//   lst rows [0,Bg)    = d(-critic_real)/dh_real = -wb * w2 * s(h_real)
+//       rows [Bg,2Bg)  = d(+critic_fake)/dh_fake = +wb * w2 * s(h_fake)
+//       rows [2Bg,3Bg) = v = s(h_hat) * w2,  h_hat = alpha h_real + (1 - alpha) h_fake   (fc1 is affine: no third GEMM)
+//   dhs = lst[real] + lst[fake] (label half / bias gradient), sl = s(h_hat)
+//   dw2 += sum_b wb (lrelu(h_fake) - lrelu(h_real));  d fc2.bias is exactly -sum wb + sum wb = 0 (the reference's
+//   autograd gives 0.0 too) and is left untouched;  cost += critic_fake - critic_real (fc2.bias cancels).
+template <int V>
+__global__ __launch_bounds__(256) void critic_head_kernel(const float* __restrict__ hf, const float* __restrict__ lh,
+                                                          const float* __restrict__ w2, const float* __restrict__ sim,
+                                                          const float* __restrict__ alpha, float* __restrict__ lst,
+                                                          float* __restrict__ dhs, float* __restrict__ sl, float* dw2,
+                                                          float* cost, int Bg, int H) {
+    __shared__ float red[4][64 * V];
+    __shared__ float redc[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * V;
+    const bool live = col < H;
+    const int r0 = blockIdx.y * HEAD_RB, r1 = min(Bg, r0 + HEAD_RB);
+    const float inv_bg = 1.f / (float)Bg;
+    VecF<V> w, acc;
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc.v[i] = 0.f, w.v[i] = 0.f;
+    if (live) w = ldv<V>(w2 + col);
+    float c = 0.f;
+    if (live) {
+        for (int r = r0 + wv; r < r1; r += 4) {
+            const float wb = (sim ? sim[r] : 1.f) * inv_bg, a = alpha[r];
+            const long long o = (long long)r * H + col;
+            const VecF<V> l = ldv<V>(lh + o), fr = ldv<V>(hf + o), fk = ldv<V>(hf + (long long)Bg * H + o);
+            VecF<V> dr, dk, vv, ds, ss;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float hr = fr.v[i] + l.v[i], hk = fk.v[i] + l.v[i];
+                const float sr = hr > 0.f ? 1.f : 0.2f, sk = hk > 0.f ? 1.f : 0.2f;
+                const float hh = a * hr + (1.f - a) * hk;
+                const float sh = hh > 0.f ? 1.f : 0.2f;
+                dr.v[i] = -wb * w.v[i] * sr;
+                dk.v[i] = wb * w.v[i] * sk;
+                vv.v[i] = sh * w.v[i];
+                ds.v[i] = dr.v[i] + dk.v[i];
+                ss.v[i] = sh;
+                const float diff = (hk > 0.f ? hk : 0.2f * hk) - (hr > 0.f ? hr : 0.2f * hr);
+                acc.v[i] += wb * diff;
+                c += wb * diff * w.v[i];
+            }
+            stv<V>(lst + o, dr);
+            stv<V>(lst + (long long)Bg * H + o, dk);
+            stv<V>(lst + 2ll * Bg * H + o, vv);
+            stv<V>(dhs + o, ds);
+            stv<V>(sl + o, ss);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[wv][lane * V + i] = acc.v[i];
+    c = wave_sum(c);
+    if (lane == 0) redc[wv] = c;
+    __syncthreads();
+    if (wv == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int k = lane * V + i;
+            atomicAdd(dw2 + col + i, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+        }
+    }
+    if (threadIdx.x == 0) atomicAdd(cost, redc[0] + redc[1] + redc[2] + redc[3]);
+}
+
+// Generator iteration (train_gan.py:299-306): the critic is frozen, only d(-critic_fake)/dh is needed.
+//   h = hf + lh;  dh = -wb * w2 * s(h);  cost += -sum_b wb (lrelu(h_b) . w2 + b2)
+template <int V>
+__global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__ hf, const float* __restrict__ lh,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       const float* __restrict__ sim, float* __restrict__ dh, float* cost,
+                                                       int Bg, int H) {
+    __shared__ float redc[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * V;
+    const bool live = col < H;
+    const int r0 = blockIdx.y * HEAD_RB, r1 = min(Bg, r0 + HEAD_RB);
+    const float inv_bg = 1.f / (float)Bg;
+    VecF<V> w;
+#pragma unroll
+    for (int i = 0; i < V; ++i) w.v[i] = 0.f;
+    if (live) w = ldv<V>(w2 + col);
+    float c = 0.f;
+    for (int r = r0 + wv; r < r1; r += 4) {
+        const float wb = (sim ? sim[r] : 1.f) * inv_bg;
+        if (blockIdx.x == 0 && lane == 0) c -= wb * b2[0];
+        if (!live) continue;
+        const long long o = (long long)r * H + col;
+        const VecF<V> l = ldv<V>(lh + o), f = ldv<V>(hf + o);
+        VecF<V> d;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float h = f.v[i] + l.v[i];
+            d.v[i] = -wb * w.v[i] * (h > 0.f ? 1.f : 0.2f);
+            c -= wb * w.v[i] * (h > 0.f ? h : 0.2f * h);
+        }
+        stv<V>(dh + o, d);
+    }
+    c = wave_sum(c);
+    if (lane == 0) redc[wv] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(cost, redc[0] + redc[1] + redc[2] + redc[3]);
+}
+
+// dw2[j] += sum_b dv[b,j] * s[b,j] with the column-owner layout of the head kernels
+template <int V>
+__global__ __launch_bounds__(256) void gp_dw2_cols_kernel(const float* __restrict__ dv, const float* __restrict__ s,
+                                                          float* dw2, int Bg, int H) {
+    __shared__ float red[4][64 * V];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * V;
+    const bool live = col < H;
+    const int r0 = blockIdx.y * HEAD_RB, r1 = min(Bg, r0 + HEAD_RB);
+    VecF<V> acc;
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc.v[i] = 0.f;
+    if (live) {
+        for (int r = r0 + wv; r < r1; r += 4) {
+            const long long o = (long long)r * H + col;
+            const VecF<V> a = ldv<V>(dv + o), b = ldv<V>(s + o);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc.v[i] += a.v[i] * b.v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[wv][lane * V + i] = acc.v[i];
+    __syncthreads();
+    if (wv == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int k = lane * V + i;
+            atomicAdd(dw2 + col + i, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+        }
+    }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad) over a FLAT parameter buffer; the step counter lives on the device so
+// that a recorded HIP graph replays correctly.  state[0] = steps taken, state[1] = ticket counter: every workgroup
+// reads the step count before it takes its ticket, the last one to finish publishes step + 1 and resets the tickets.
+//   m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                        float b1, float b2, float eps, int* state) {
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) {
+        const int t = *(volatile int*)state + 1;
+        const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+        sh[0] = (float)((double)lr / bc1);
+        sh[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float step_size = sh[0], bc2_sqrt = sh[1];
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = mm[k] + (gg[k] - mm[k]) * (1.f - b1);
+            vv[k] = vv[k] * b2 + (1.f - b2) * gg[k] * gg[k];
+            pp[k] -= step_size * (mm[k] / (sqrtf(vv[k]) / bc2_sqrt + eps));
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+            const float gg = g[i];
+            const float mm = m[i] + (gg - m[i]) * (1.f - b1);
+            const float vv = v[i] * b2 + (1.f - b2) * gg * gg;
+            m[i] = mm, v[i] = vv;
+            p[i] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(state + 1, 1);
+        if (ticket == (int)gridDim.x - 1) {
+            const int t = *(volatile int*)state + 1;
+            *(volatile int*)state = t;
+            *(volatile int*)(state + 1) = 0;
+            __threadfence();
+        }
+    }
+}
+
+extern "C" int gzsl_gan_critic_head(const float* hf, const float* lh, const float* w2, const float* sim,
+                                    const float* alpha, float* lst, float* dhs, float* sl, float* dw2, float* cost, int Bg,
+                                    int H, void* stream) {
+    if (Bg <= 0 || H <= 0) return 0;
+    const bool v4 = (H & 3) == 0 && al16(hf) && al16(lh) && al16(w2) && al16(lst) && al16(dhs) && al16(sl);
+    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, HEAD_RB)), block(256);
+    if (v4)
+        hipLaunchKernelGGL(critic_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H);
+    else
+        hipLaunchKernelGGL(critic_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_gan_gen_head(const float* hf, const float* lh, const float* w2, const float* b2, const float* sim,
+                                 float* dh, float* cost, int Bg, int H, void* stream) {
+    if (Bg <= 0 || H <= 0) return 0;
+    const bool v4 = (H & 3) == 0 && al16(hf) && al16(lh) && al16(w2) && al16(dh);
+    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, HEAD_RB)), block(256);
+    if (v4) hipLaunchKernelGGL(gen_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, b2, sim, dh, cost, Bg, H);
+    else hipLaunchKernelGGL(gen_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, b2, sim, dh, cost, Bg, H);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gzsl_adam_flat_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                                   float beta2, float eps, int* state, void* stream) {
+    if (n <= 0) return 0;
+    if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return GZSL_EINVAL;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((int)blocks), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, state);
+    GZSL_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int gzsl_gp_interp(const float* real, const float* fake, const float* alpha, float* out, int Bg, int D,
@@ -197,15 +516,19 @@ extern "C" int gzsl_gp_slope_v(const float* h, const float* w2, float* v, float*
 
 extern "C" int gzsl_gp_rownorm(float* g, float* gp, int Bg, int D, float lam, void* stream) {
     if (Bg <= 0) return 0;
-    hipLaunchKernelGGL(gp_rownorm_kernel, dim3(min(ew_blocks(Bg, 4), 1024)), dim3(256), 0, ST, g, gp, Bg, D, lam);
+    const dim3 grid(min(cdiv(Bg, 4), 2048)), block(256);
+    if ((D & 3) == 0 && al16(g)) hipLaunchKernelGGL(gp_rownorm_kernel<4>, grid, block, 0, ST, g, gp, Bg, D, lam);
+    else hipLaunchKernelGGL(gp_rownorm_kernel<1>, grid, block, 0, ST, g, gp, Bg, D, lam);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gzsl_gp_dw2(const float* dv, const float* s, float* dw2, int Bg, int H, void* stream) {
     if (Bg <= 0) return 0;
-    const int rpb = 64;
-    hipLaunchKernelGGL(gp_dw2_kernel, dim3(cdiv(H, 256), cdiv(Bg, rpb)), dim3(256), 0, ST, dv, s, dw2, Bg, H, rpb);
+    const bool v4 = (H & 3) == 0 && al16(dv) && al16(s);
+    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, HEAD_RB)), block(256);
+    if (v4) hipLaunchKernelGGL(gp_dw2_cols_kernel<4>, grid, block, 0, ST, dv, s, dw2, Bg, H);
+    else hipLaunchKernelGGL(gp_dw2_cols_kernel<1>, grid, block, 0, ST, dv, s, dw2, Bg, H);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
@@ -237,11 +560,28 @@ extern "C" int gzsl_rowdot_bwd(const float* dout, const float* w, const float* a
     return 0;
 }
 
-extern "C" int gzsl_keyword_ce(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* w,
-                               float* loss_b, int Bg, int Vk, int top_k, void* stream) {
+static int keyword_ce_launch(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* w, float* loss_b,
+                             int Bg, int Vk, int top_k, int sim_mode, float grad_scale, float loss_scale, float* loss_sum,
+                             void* stream) {
     if (Bg <= 0) return 0;
     if (Vk <= 0 || top_k <= 0) return GZSL_EINVAL;
-    hipLaunchKernelGGL(keyword_ce_kernel, dim3(Bg), dim3(256), 0, ST, logits, kw_idx, kw_mask, w, loss_b, Bg, Vk, top_k);
+    if ((Vk & 3) == 0 && Vk <= 8192 && al16(logits))
+        hipLaunchKernelGGL(keyword_ce_kernel<true>, dim3(Bg), dim3(256), 0, ST, logits, kw_idx, kw_mask, w, loss_b, Bg, Vk,
+                           top_k, sim_mode, grad_scale, loss_scale, loss_sum);
+    else
+        hipLaunchKernelGGL(keyword_ce_kernel<false>, dim3(Bg), dim3(256), 0, ST, logits, kw_idx, kw_mask, w, loss_b, Bg, Vk,
+                           top_k, sim_mode, grad_scale, loss_scale, loss_sum);
     GZSL_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int gzsl_keyword_ce(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* w,
+                               float* loss_b, int Bg, int Vk, int top_k, void* stream) {
+    return keyword_ce_launch(logits, kw_idx, kw_mask, w, loss_b, Bg, Vk, top_k, 0, 1.f, 1.f, nullptr, stream);
+}
+
+extern "C" int gzsl_keyword_ce_sim(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* sim,
+                                   float grad_scale, float loss_scale, float* loss_b, float* loss_sum, int Bg, int Vk,
+                                   int top_k, void* stream) {
+    return keyword_ce_launch(logits, kw_idx, kw_mask, sim, loss_b, Bg, Vk, top_k, 1, grad_scale, loss_scale, loss_sum, stream);
 }

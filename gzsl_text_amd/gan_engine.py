@@ -14,21 +14,51 @@ What differs from "run the reference's ops one by one":
 Sign conventions follow the driver: critic grads = d(-critic_real + critic_fake + gp), generator grads =
 d(-critic_fake + reg_ratio * keyword_loss) (train_gan.py:244-256, 300-306).
 """
+import math
+
 import torch
 
 from .hip import ACT_LRELU, ACT_NONE, ACT_RELU
 
 
-def zero_grads(params, skip=()):
-    """Zero gradient tensors for a parameter dict, carved out of ONE flat buffer (one fill launch instead of one per tensor)."""
-    keys = [k for k in params if k not in skip]
-    flat = torch.zeros(sum(params[k].numel() for k in keys), dtype=torch.float32, device=params[keys[0]].device)
-    out, off = {}, 0
-    for k in keys:
-        n = params[k].numel()
-        out[k] = flat[off:off + n].view_as(params[k])
-        off += n
-    return out
+class Layout:
+    """Where each tensor of an ordered (key, shape) list sits in ONE flat fp32 buffer.  Every offset is a multiple of 64
+    floats (256 bytes), so views are valid operands for the 16-byte vector paths of the kernels.  Parameters, their
+    gradients and Adam's moments share a layout: one fill zeroes all gradients of an iteration, one launch updates all
+    parameters (gzsl_adam_flat_step)."""
+    ALIGN = 64
+
+    def __init__(self, items):
+        self.offs, off = {}, 0
+        for k, shape in items:
+            n = math.prod(shape)
+            self.offs[k] = (off, n, tuple(shape))
+            off += -(-n // self.ALIGN) * self.ALIGN
+        self.size = off
+
+    @classmethod
+    def of(cls, params, skip=(), prefix=''):
+        return cls([(prefix + k, v.shape) for k, v in params.items() if k not in skip])
+
+    def views(self, flat):
+        return {k: flat[o:o + n].view(shape) for k, (o, n, shape) in self.offs.items()}
+
+    def __add__(self, other):
+        out = Layout([])
+        out.offs = dict(self.offs)
+        for k, (o, n, shape) in other.offs.items():
+            out.offs[k] = (self.size + o, n, shape)
+        out.size = self.size + other.size
+        return out
+
+
+N_SCALARS = 64  # tail of every gradient buffer: [0], [1] hold the iteration's two scalar results
+
+
+def zero_grads(layout, device):
+    """(flat gradient buffer incl. the scalar tail, views by key, scalar tail) -- one fill launch for all of it."""
+    flat = torch.zeros(layout.size + N_SCALARS, dtype=torch.float32, device=device)
+    return flat[:layout.size], layout.views(flat), flat[layout.size:]
 
 
 class GanEngine:
@@ -36,14 +66,14 @@ class GanEngine:
         self.ops = ops
 
     # ------------------------------------------------------------------------------------------ generator
-    def generator_fwd(self, g, noise, lab, relu_out=True):
+    def generator_fwd(self, g, noise, lab, relu_out=True, out=None):
         """relu(G(noise, lab)) (generative_module.py:48-53 + train_gan.py:248).  Returns (fake, hidden activations)."""
         ops = self.ops
         n1 = noise.shape[1]
         W1 = g['fc1.weight']
         h = ops.mm(noise, W1[:, :n1].t(), bias=g['fc1.bias'])
         ops.mm(lab, W1[:, n1:].t(), out=h, accumulate=True, act=ACT_LRELU)
-        fake = ops.mm(h, g['fc2.weight'].t(), bias=g['fc2.bias'], act=ACT_RELU if relu_out else ACT_NONE)
+        fake = ops.mm(h, g['fc2.weight'].t(), out=out, bias=g['fc2.bias'], act=ACT_RELU if relu_out else ACT_NONE)
         return fake, h
 
     def generator_bwd(self, dfake, fake, h, g, noise, lab, G, relu_out=True):
@@ -119,105 +149,146 @@ class GanEngine:
         return loss_b, dfake
 
     # ------------------------------------------------------------------------------------------ iterations
+    # The whole-iteration forms below are what WganGpStep runs.  They stack rows so that each product is ONE GEMM:
+    #   F   = [real; fake; d gp/d gvec]         [3Bg, D]     hf = F[:2Bg] @ W1f^T  (both critic evaluations)
+    #   lst = [dh_real; dh_fake; v]             [3Bg, ndh]   d fc1.weight[:, :D] = lst^T @ F  (K = 3Bg, no accumulation)
+    # and run everything between those GEMMs in one kernel (gzsl_gan_critic_head / gzsl_gan_gen_head).  Every gradient
+    # tensor is written by exactly one GEMM / column sum, or accumulated by kernels ordered on the stream.
     def critic_iteration(self, d, g, real, lab, noise, alpha, sim=None, lam=10.0):
-        """train_gan.py:228-259 up to optimizer_d.step().  Returns (d_cost, gp, grads for d, fake)."""
+        """train_gan.py:228-259 up to optimizer_d.step().  Returns (d_cost, gp, grads for d, fake); the grads dict
+        carries `.flat`, the buffer its tensors are views of (laid out as Layout.of(d))."""
         ops = self.ops
         Bg, D = real.shape
-        G = zero_grads(d)
-        w = torch.full((Bg,), 1.0 / Bg, device=real.device) if sim is None else (sim * (1.0 / Bg)).contiguous()
-        lab_half = self.critic_label_half(d, lab, D)
-        real_logits, h_real = self.critic_fwd(d, real, lab_half)
-        fake, _ = self.generator_fwd(g, noise, lab)
-        fake_logits, h_fake = self.critic_fwd(d, fake, lab_half)
-        critic_real = ops.weighted_sum(real_logits, w, 1.0)
-        critic_fake = ops.weighted_sum(fake_logits, w, 1.0)
-        dh_real = self.critic_bwd((-w).contiguous(), h_real, d, G)
-        dh_fake = self.critic_bwd(w, h_fake, d, G)
-        self.critic_fc1_grads(dh_real, real, None, G)
-        self.critic_fc1_grads(dh_fake, fake, None, G)
-        dh_sum = dh_real.add_(dh_fake)
-        ops.mm(dh_sum.t(), lab, out=G['fc1.weight'][:, D:], accumulate=True)
-        ops.colsum(dh_sum, out=G['fc1.bias'])
-        gp = self.gradient_penalty(d, h_real, h_fake, alpha, D, G, lam)
-        return critic_fake - critic_real, gp, G, fake
+        flat, views, scal = zero_grads(Layout.of(d), real.device)
+        G = GradDict(views, flat)
+        W1f, w2 = d['fc1.weight'][:, :D], d['fc2.weight'][0]
+        F = torch.empty((3 * Bg, D), dtype=torch.float32, device=real.device)
+        F[:Bg].copy_(real)
+        fake = F[Bg:2 * Bg]
+        self.generator_fwd(g, noise, lab, out=fake)
+        lh = self.critic_label_half(d, lab, D)
+        hf = ops.mm(F[:2 * Bg], W1f.t())
+        lst, dhs, sl = ops.gan_critic_head(hf, lh, w2, sim, alpha.reshape(-1), G['fc2.weight'][0], scal[0:1])
+        gvec = ops.mm(lst[2 * Bg:], W1f, out=F[2 * Bg:])
+        ops.gp_rownorm_(gvec, lam, out=scal[1:2])  # gvec <- d gp / d gvec
+        dv = ops.mm(gvec, W1f.t())
+        ops.gp_dw2_(dv, sl, G['fc2.weight'][0])
+        ops.mm(lst.t(), F, out=G['fc1.weight'][:, :D])
+        ops.mm(dhs.t(), lab, out=G['fc1.weight'][:, D:])
+        ops.colsum(dhs, out=G['fc1.bias'])
+        return scal[0], scal[1], G, fake
 
     def generator_iteration(self, d, g, kw, lab, noise, sim=None, kw_idx=None, kw_mask=None, reg_ratio=0.0):
-        """train_gan.py:262-306 up to optimizer_g.step().  Returns (g_cost, keyword_loss, grads g, grads kw, fake)."""
+        """train_gan.py:262-306 up to optimizer_g.step().  Returns (g_cost, keyword_loss, grads g, grads kw, fake); the
+        two grads dicts are views of ONE flat buffer (`Gg.flat`, laid out as Layout.of(g) + Layout.of(kw head))."""
         ops = self.ops
         Bg = lab.shape[0]
-        Gg = zero_grads(g)
-        w = torch.full((Bg,), 1.0 / Bg, device=lab.device) if sim is None else (sim * (1.0 / Bg)).contiguous()
-        fake, h = self.generator_fwd(g, noise, lab)
+        use_kw = reg_ratio > 0
+        lay = Layout.of(g, prefix='g.')
+        if use_kw:
+            lay = lay + Layout.of(kw, skip=('word_emb',), prefix='kw.')
+        flat, views, scal = zero_grads(lay, lab.device)
+        Gg = GradDict({k[2:]: v for k, v in views.items() if k.startswith('g.')}, flat)
+        Gk = GradDict({k[3:]: v for k, v in views.items() if k.startswith('kw.')}, flat) if use_kw else None
+        xin = torch.cat([noise, lab], 1)
+        h = ops.mm(xin, g['fc1.weight'].t(), bias=g['fc1.bias'], act=ACT_LRELU)
+        fake = ops.mm(h, g['fc2.weight'].t(), bias=g['fc2.bias'], act=ACT_RELU)
         D = fake.shape[1]
-        Gk, kw_loss = None, torch.zeros((), device=lab.device)
         dfake = None
-        if reg_ratio > 0:
-            Gk = zero_grads(kw, skip=('word_emb',))
-            kww = torch.ones(Bg, device=lab.device) if sim is None else torch.where(sim != 1, torch.zeros_like(sim), sim)
-            loss_b, dfake = self.keyword_fwd_bwd(kw, fake, kw_idx, kw_mask, (kww * (reg_ratio / Bg)).contiguous(), Gk)
-            kw_loss = ops.weighted_sum(loss_b, kww.contiguous(), 1.0 / Bg)
-        lab_half = self.critic_label_half(d, lab, D)
-        fake_logits, h_d = self.critic_fwd(d, fake, lab_half)
-        g_cost = -ops.weighted_sum(fake_logits, w, 1.0)
-        dh = self.critic_bwd((-w).contiguous(), h_d, d, None)
+        if use_kw:  # decoder_module.py:39-59 with train_gan.py:288-296's row weights
+            Wp, We = kw['proj_fc.weight'], kw['word_emb']
+            xk = ops.mm(fake, Wp.t(), bias=kw['proj_fc.bias'])
+            logits = ops.mm(xk, We.t())
+            ops.keyword_ce_sim_(logits, kw_idx, kw_mask, sim, reg_ratio / Bg, 1.0 / Bg, scal[1:2])  # logits <- d / d logits
+            dxk = ops.mm(logits, We)
+            ops.mm(dxk.t(), fake, out=Gk['proj_fc.weight'])
+            ops.colsum(dxk, out=Gk['proj_fc.bias'])
+            dfake = ops.mm(dxk, Wp)
         W1f = d['fc1.weight'][:, :D]
-        if dfake is None:
-            dfake = ops.mm(dh, W1f)
-        else:
-            ops.mm(dh, W1f, out=dfake, accumulate=True)
-        self.generator_bwd(dfake, fake, h, g, noise, lab, Gg)
-        return g_cost, kw_loss, Gg, Gk, fake
+        lh = self.critic_label_half(d, lab, D)
+        hf = ops.mm(fake, W1f.t())
+        dh = ops.gan_gen_head(hf, lh, d['fc2.weight'][0], d['fc2.bias'], sim, scal[0:1])
+        dfake = ops.mm(dh, W1f, out=dfake, accumulate=dfake is not None)
+        ops.act_bwd_(dfake, fake, ACT_RELU)
+        ops.mm(dfake.t(), h, out=Gg['fc2.weight'])
+        ops.colsum(dfake, out=Gg['fc2.bias'])
+        dhg = ops.mm(dfake, g['fc2.weight'])
+        ops.act_bwd_(dhg, h, ACT_LRELU)
+        ops.mm(dhg.t(), xin, out=Gg['fc1.weight'])
+        ops.colsum(dhg, out=Gg['fc1.bias'])
+        return scal[0], scal[1], Gg, Gk, fake
+
+
+class GradDict(dict):
+    """Gradient tensors by parameter name + `.flat`, the one buffer they are views of."""
+
+    def __init__(self, views, flat):
+        super().__init__(views)
+        self.flat = flat
 
 
 class WganGpStep:
     """One full WGAN-GP step = `critic_iters` critic iterations + one generator iteration with Adam(betas .5/.999),
-    as train_gan.py:223-308 orders them.  Parameters live in dicts of tensors (same keys as the reference's
-    `generator` / `discriminator` / keyword-head state dicts); torch.optim.Adam does the updates."""
+    as train_gan.py:223-308 orders them (optimizers: train_gan.py:155-157).
 
-    def __init__(self, ops, g, d, kw=None, lr=1e-4, critic_iters=5, reg_ratio=0.0, lam=10.0, capturable=False):
-        self.eng = GanEngine(ops)
-        self.g, self.d, self.kw = g, d, kw
+    The parameter dicts passed in (same keys as the reference's `generator` / `discriminator` / keyword-head state
+    dicts) are MOVED into flat buffers: read the live parameters from `.g`, `.d`, `.kw` afterwards.  The critic is one
+    buffer, generator + keyword head another (the reference gives those two to one optimizer), so an optimizer step is
+    one launch of gzsl_adam_flat_step; its step counter lives on the device, which makes the whole step recordable into
+    a HIP graph (`graphed_step` below) without further switches."""
+
+    def __init__(self, ops, g, d, kw=None, lr=1e-4, critic_iters=5, reg_ratio=0.0, lam=10.0, betas=(0.5, 0.999),
+                 eps=1e-8, capturable=None):
+        self.eng, self.ops = GanEngine(ops), ops
         self.critic_iters, self.reg_ratio, self.lam = critic_iters, reg_ratio, lam
-        for t in list(g.values()) + list(d.values()):
-            t.requires_grad_(False)
-        self._gp = {k: torch.nn.Parameter(v, requires_grad=False) for k, v in g.items()}
-        self._dp = {k: torch.nn.Parameter(v, requires_grad=False) for k, v in d.items()}
-        self._kp = {} if kw is None else {k: torch.nn.Parameter(v, requires_grad=False)
-                                          for k, v in kw.items() if k != 'word_emb'}
-        # capturable=True keeps Adam's step counters on the device, so a whole step can be recorded into a HIP graph
-        # (`graphed_step` below): at the drivers' default batch of 8 the step is ~300 launches of microsecond kernels
-        extra = {'capturable': True} if capturable else {}
-        if all(t.is_cuda for t in list(g.values()) + list(d.values())):
-            extra['fused'] = True  # one multi-tensor launch per step() instead of ~8 elementwise passes (0.6 ms per
-            #                        WGAN-GP step at any batch size: 6 optimizer steps x 8 launches of 10-15 us)
-        self.opt_d = torch.optim.Adam(list(self._dp.values()), lr=lr, betas=(0.5, 0.999), **extra)
-        self.opt_g = torch.optim.Adam(list(self._gp.values()) + list(self._kp.values()), lr=lr, betas=(0.5, 0.999),
-                                      **extra)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        dev = d['fc1.weight'].device
+        self._use_kw = kw is not None and reg_ratio > 0
+        self.d, self._pd = self._rehome(Layout.of(d), {k: v for k, v in d.items()}, dev)
+        lay_g, src = Layout.of(g, prefix='g.'), {'g.' + k: v for k, v in g.items()}
+        if self._use_kw:
+            lay_g = lay_g + Layout.of(kw, skip=('word_emb',), prefix='kw.')
+            src.update({'kw.' + k: v for k, v in kw.items() if k != 'word_emb'})
+        views, self._pg = self._rehome(lay_g, src, dev)
+        self.g = {k[2:]: v for k, v in views.items() if k.startswith('g.')}
+        self.kw = kw
+        if self._use_kw:
+            self.kw = {k[3:]: v for k, v in views.items() if k.startswith('kw.')}
+            self.kw['word_emb'] = kw['word_emb']
+        self._opt = {}
+        for name, p in (('d', self._pd), ('g', self._pg)):
+            self._opt[name] = (torch.zeros_like(p), torch.zeros_like(p), torch.zeros(2, dtype=torch.int32, device=dev))
+
+    @staticmethod
+    def _rehome(layout, src, dev):
+        flat = torch.zeros(layout.size, dtype=torch.float32, device=dev)
+        views = layout.views(flat)
+        for k, v in views.items():
+            v.copy_(src[k])
+        return views, flat
+
+    def _adam(self, name, p, gflat):
+        m, v, state = self._opt[name]
+        self.ops.adam_flat_step_(p, gflat, m, v, state, self.lr, self.betas[0], self.betas[1], self.eps)
 
     def critic_step(self, real, lab, noise, alpha, sim=None):
         d_cost, gp, G, fake = self.eng.critic_iteration(self.d, self.g, real, lab, noise, alpha, sim, self.lam)
-        for k, p in self._dp.items():
-            p.grad = G[k]
-        self.opt_d.step()
+        self._adam('d', self._pd, G.flat)
         return d_cost, gp, G, fake
 
     def generator_step(self, lab, noise, sim=None, kw_idx=None, kw_mask=None):
         g_cost, kw_loss, Gg, Gk, fake = self.eng.generator_iteration(self.d, self.g, self.kw, lab, noise, sim, kw_idx,
-                                                                     kw_mask, self.reg_ratio)
-        for k, p in self._gp.items():
-            p.grad = Gg[k]
-        for k, p in self._kp.items():
-            p.grad = Gk[k]
-        self.opt_g.step()
+                                                                     kw_mask, self.reg_ratio if self._use_kw else 0.0)
+        self._adam('g', self._pg, Gg.flat)
         return g_cost, kw_loss, Gg, Gk, fake
 
 
 def graphed_step(fn, warmup=3):
-    """Record `fn()` (a full WGAN-GP step over STATIC input tensors, built with `capturable=True`) into one HIP graph
+    """Record `fn()` (a full WGAN-GP step of a WganGpStep over STATIC input tensors) into one HIP graph
     and return a replay callable.  Launch-bound at small batches (train_gan.py's default batch is 8): the eager step is
     a few hundred kernel launches from Python, the replay is one graph launch.  The caller refreshes the static input
     tensors in place between replays; the outputs of `fn` recorded at capture time are returned by every replay."""
-    if warmup < 1:  # state created lazily inside the recording (Adam's moments) would be re-zeroed by every replay
+    if warmup < 1:  # lazily created state (library handles, workspaces) must exist before the recording
         raise ValueError('graphed_step needs at least one eager warm-up step before the recording')
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

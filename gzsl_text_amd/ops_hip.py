@@ -387,8 +387,9 @@ class HipOps:
         call('gzsl_gp_slope_v', ptr(h), ptr(w2), ptr(v), ptr(s), h.shape[0], h.shape[1])
         return v, s
 
-    def gp_rownorm_(self, g, lam):
-        gp = torch.zeros((), dtype=torch.float32, device=g.device)
+    def gp_rownorm_(self, g, lam, out=None):
+        """g <- d gp / d g in place; the penalty is ADDED to `out` (a zeroed 1-element tensor; allocated when None)."""
+        gp = torch.zeros((), dtype=torch.float32, device=g.device) if out is None else out
         call('gzsl_gp_rownorm', ptr(g), ptr(gp), g.shape[0], g.shape[1], float(lam))
         return gp
 
@@ -410,6 +411,37 @@ class HipOps:
         call('gzsl_rowdot_bwd', ptr(dout), ptr(w), ptr(act), ptr(da), ptr(dw), ptr(db), act.shape[0], act.shape[1],
              int(lrelu_in))
         return da
+
+    def gan_critic_head(self, hf, lh, w2, sim, alpha, dw2, cost):
+        """gzsl_gan_critic_head: returns (lst [3Bg,H], dhs [Bg,H], sl [Bg,H]); dw2 / cost are accumulated."""
+        Bg, H = lh.shape
+        assert hf.shape == (2 * Bg, H) and alpha.numel() == Bg and (sim is None or sim.numel() == Bg)
+        lst = torch.empty((3 * Bg, H), dtype=torch.float32, device=lh.device)
+        dhs, sl = torch.empty_like(lh), torch.empty_like(lh)
+        call('gzsl_gan_critic_head', ptr(hf), ptr(lh), ptr(w2), ptr(sim), ptr(alpha), ptr(lst), ptr(dhs), ptr(sl), ptr(dw2),
+             ptr(cost), Bg, H)
+        return lst, dhs, sl
+
+    def gan_gen_head(self, hf, lh, w2, b2, sim, cost):
+        Bg, H = lh.shape
+        assert hf.shape == (Bg, H) and (sim is None or sim.numel() == Bg)
+        dh = torch.empty_like(lh)
+        call('gzsl_gan_gen_head', ptr(hf), ptr(lh), ptr(w2), ptr(b2), ptr(sim), ptr(dh), ptr(cost), Bg, H)
+        return dh
+
+    def adam_flat_step_(self, p, g, m, v, state, lr, beta1, beta2, eps):
+        """torch.optim.Adam.step over one flat buffer; `state` = int32 [2] on the device (step count, ticket)."""
+        assert p.numel() == g.numel() == m.numel() == v.numel() and state.dtype == torch.int32 and state.numel() == 2
+        call('gzsl_adam_flat_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, ptr(state))
+
+    def keyword_ce_sim_(self, logits, kw_idx, kw_mask, sim, grad_scale, loss_scale, loss_sum):
+        """keyword_ce_ with train_gan.py:288-296's row weights computed from `sim` inside the kernel; the weighted loss
+        sum is ADDED to `loss_sum` (1 element)."""
+        Bg, Vk = logits.shape
+        loss_b = torch.empty(Bg, dtype=torch.float32, device=logits.device)
+        call('gzsl_keyword_ce_sim', ptr(logits), ptr(kw_idx), ptr(kw_mask), ptr(sim), float(grad_scale), float(loss_scale),
+             ptr(loss_b), ptr(loss_sum), Bg, Vk, kw_idx.shape[1])
+        return loss_b
 
     def keyword_ce_(self, logits, kw_idx, kw_mask, w):
         """Returns per-row loss; overwrites `logits` with w_b * d loss_b / d logits."""

@@ -196,6 +196,32 @@ int gzsl_rowdot_bwd(const float* dout, const float* w, const float* act, float* 
 int gzsl_keyword_ce(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* w, float* loss_b, int Bg,
                     int Vk, int top_k, void* stream);
 
+/* Same with the driver's row weighting folded in (train_gan.py:288-296): keywords_weight_b = (sim == NULL || sim[b] == 1)
+ * ? 1 : 0; dlogits rows are scaled by keywords_weight_b * grad_scale and *loss_sum += loss_b * keywords_weight_b *
+ * loss_scale (atomic; loss_sum may be NULL). */
+int gzsl_keyword_ce_sim(float* logits, const int64_t* kw_idx, const float* kw_mask, const float* sim, float grad_scale,
+                        float loss_scale, float* loss_b, float* loss_sum, int Bg, int Vk, int top_k, void* stream);
+/* One critic iteration's elementwise middle in one launch (train_gan.py:244-256, generative_module.py:22-38, 59-68):
+ * between the fc1 GEMMs and the gradient GEMMs.  hf [2Bg,H] = [real; fake] @ fc1.weight[:, :D]^T, lh [Bg,H] = lab @
+ * fc1.weight[:, D:]^T + fc1.bias; pre-activations h = hf + lh; wb = sim[b]/Bg (sim NULL: 1/Bg); slope s in {1, 0.2}.
+ *   lst [3Bg,H]: rows [0,Bg) = -wb*w2*s(h_real), [Bg,2Bg) = +wb*w2*s(h_fake), [2Bg,3Bg) = s(h_hat)*w2 with
+ *   h_hat = alpha*h_real + (1-alpha)*h_fake;  dhs [Bg,H] = the first two row blocks added;  sl [Bg,H] = s(h_hat);
+ *   dw2[j] += sum_b wb*(lrelu(h_fake) - lrelu(h_real))[b,j]   (atomic);   *cost += critic_fake - critic_real (atomic).
+ * d fc2.bias of the critic objective is identically 0 and is not written. */
+int gzsl_gan_critic_head(const float* hf, const float* lh, const float* w2, const float* sim, const float* alpha,
+                         float* lst, float* dhs, float* sl, float* dw2, float* cost, int Bg, int H, void* stream);
+/* Generator iteration (train_gan.py:299-306), critic frozen: dh[b,j] = -wb*w2[j]*s(h[b,j]), h = hf + lh [Bg,H];
+ * *cost += -sum_b wb*(lrelu(h_b) . w2 + b2[0]) (atomic). */
+int gzsl_gan_gen_head(const float* hf, const float* lh, const float* w2, const float* b2, const float* sim, float* dh,
+                      float* cost, int Bg, int H, void* stream);
+/* torch.optim.Adam.step (train_gan.py:155-157: betas (0.5, 0.999), no weight decay, no amsgrad) over ONE flat buffer of
+ * n parameters (16-byte aligned): m += (g-m)(1-beta1); v = beta2 v + (1-beta2) g^2;
+ * p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps).  state [2] int32, zero before the first step: state[0] =
+ * steps taken (read, then incremented by the last workgroup to finish), state[1] = ticket counter.  The step count
+ * lives on the device so that a recorded HIP graph replays with the right bias correction. */
+int gzsl_adam_flat_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                        float eps, int* state, void* stream);
+
 /* library self-description: number of exported compute entry points and build target string */
 const char* gzsl_build_info(void);
 

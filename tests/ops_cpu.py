@@ -253,13 +253,16 @@ class CpuOps:
         s = torch.where(h > 0, torch.ones_like(h), torch.full_like(h, 0.2))
         return s * w2[None, :], s
 
-    def gp_rownorm_(self, g, lam):
+    def gp_rownorm_(self, g, lam, out=None):
         nrm = g.norm(2, dim=1)
         Bg = g.shape[0]
         gp = lam * ((nrm - 1) ** 2).mean()
         coef = lam * 2 * (nrm - 1) / Bg / torch.where(nrm > 0, nrm, torch.ones_like(nrm))
         g.mul_(coef[:, None])
-        return gp
+        if out is None:
+            return gp
+        out += gp
+        return out
 
     def gp_dw2_(self, dv, s, dw2):
         dw2 += (dv * s).sum(0)
@@ -281,6 +284,42 @@ class CpuOps:
         if need_da:
             return dout[:, None] * w[None, :] * torch.where(act > 0, torch.ones_like(act), torch.full_like(act, 0.2))
         return None
+
+    def gan_critic_head(self, hf, lh, w2, sim, alpha, dw2, cost):
+        Bg, H = lh.shape
+        wb = (torch.ones(Bg) if sim is None else sim) / Bg
+        hr, hk = hf[:Bg] + lh, hf[Bg:] + lh
+        a = alpha.reshape(-1, 1)
+        slope = lambda x: torch.where(x > 0, torch.ones_like(x), torch.full_like(x, 0.2))  # noqa: E731
+        hh = a * hr + (1 - a) * hk
+        dr = -wb[:, None] * w2[None] * slope(hr)
+        dk = wb[:, None] * w2[None] * slope(hk)
+        diff = F.leaky_relu(hk, 0.2) - F.leaky_relu(hr, 0.2)
+        dw2 += (wb[:, None] * diff).sum(0)
+        cost += (wb[:, None] * diff * w2[None]).sum()
+        return torch.cat([dr, dk, slope(hh) * w2[None]], 0).contiguous(), (dr + dk).contiguous(), slope(hh)
+
+    def gan_gen_head(self, hf, lh, w2, b2, sim, cost):
+        Bg, H = lh.shape
+        wb = (torch.ones(Bg) if sim is None else sim) / Bg
+        h = hf + lh
+        cost -= (wb * (F.leaky_relu(h, 0.2) @ w2 + b2[0])).sum()
+        return -wb[:, None] * w2[None] * torch.where(h > 0, torch.ones_like(h), torch.full_like(h, 0.2))
+
+    def adam_flat_step_(self, p, g, m, v, state, lr, beta1, beta2, eps):
+        t = int(state[0]) + 1
+        state[0] = t
+        m.add_((g - m) * (1 - beta1))
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        p.sub_((lr / (1 - beta1 ** t)) * m / (v.sqrt() / (1 - beta2 ** t) ** 0.5 + eps))
+
+    def keyword_ce_sim_(self, logits, kw_idx, kw_mask, sim, grad_scale, loss_scale, loss_sum):
+        Bg = logits.shape[0]
+        kww = torch.ones(Bg) if sim is None else (sim == 1).float()
+        loss_b = self.keyword_ce_(logits, kw_idx, kw_mask, kww * grad_scale)
+        if loss_sum is not None:
+            loss_sum += (loss_b * kww).sum() * loss_scale
+        return loss_b
 
     def keyword_ce_(self, logits, kw_idx, kw_mask, w):
         Bg, Vk = logits.shape

@@ -357,6 +357,70 @@ def test_gan_kernels(ops, ref):
     close(ld, lr2, 1e-5, 1e-6, 'keyword CE dlogits')
 
 
+@pytest.mark.parametrize('Bg,H,D,Vk', [(8, 800, 400, 4096), (70, 800, 400, 300), (33, 50, 37, 301), (300, 804, 1028, 8196)])
+def test_gan_iteration_kernels(ops, ref, Bg, H, D, Vk):
+    """The whole-iteration kernels of the WGAN-GP step (critic / generator head, column-owner dw2, register-resident
+    row norm and keyword CE incl. their scalar fallbacks: H, D, Vk not multiples of 4, D > 1024, Vk > 8192)."""
+    rs = np.random.RandomState(Bg + H)
+    hf, lh, w2, b2 = rnd(rs, 2 * Bg, H), rnd(rs, Bg, H), rnd(rs, H), rnd(rs, 1)
+    sim = torch.from_numpy(rs.choice([1.0, 0.4, 0.0], size=Bg).astype(np.float32))
+    alpha = torch.from_numpy(rs.random_sample(Bg).astype(np.float32))
+    for sm in (sim, None):
+        dw2, cost = torch.zeros(H, device=DEV), torch.zeros(1, device=DEV)
+        dw2r, costr = torch.zeros(H), torch.zeros(1)
+        got = ops.gan_critic_head(g(hf), g(lh), g(w2), g(sm), g(alpha), dw2, cost)
+        want = ref.gan_critic_head(hf, lh, w2, sm, alpha, dw2r, costr)
+        for a, b, nm in zip(got, want, ('lst', 'dhs', 'slopes')):
+            close(a, b, 1e-6, 1e-7, 'critic head ' + nm)
+        close(dw2, dw2r, 1e-5, 2e-6, 'critic head dw2')
+        close(cost, costr, 1e-4, 1e-5 * np.sqrt(H), 'critic head cost')
+        cost, costr = torch.zeros(1, device=DEV), torch.zeros(1)
+        close(ops.gan_gen_head(g(hf[:Bg]), g(lh), g(w2), g(b2), g(sm), cost), ref.gan_gen_head(hf[:Bg], lh, w2, b2, sm, costr),
+              1e-6, 1e-7, 'generator head dh')
+        close(cost, costr, 1e-4, 1e-5 * np.sqrt(H), 'generator head cost')
+    dv, s = rnd(rs, Bg, H), ref.gp_slope_v(lh, w2)[1]
+    dw2 = torch.zeros(H, device=DEV)
+    ops.gp_dw2_(g(dv), g(s), dw2)
+    close(dw2, (dv * s).sum(0), 1e-5, 1e-5, 'gp dw2')
+    gg = rnd(rs, Bg, D, scale=0.1)
+    ggd, acc = g(gg).clone(), torch.full((1,), 0.5, device=DEV)
+    ops.gp_rownorm_(ggd, 10.0, out=acc)
+    close((acc - 0.5)[0], ref.gp_rownorm_(gg, 10.0), 1e-5, 1e-5, 'gp value (accumulated into out)')
+    close(ggd, gg, 1e-5, 1e-7, 'gp dg')
+    K = 20
+    logits = rnd(rs, Bg, Vk)
+    kw_idx = torch.from_numpy(np.stack([rs.choice(Vk, size=K, replace=False) for _ in range(Bg)]).astype(np.int64))
+    kw_idx[:, 5] = kw_idx[:, 2]
+    kw_mask = torch.from_numpy(rs.uniform(0, 1, (Bg, K)).astype(np.float32))
+    for sm in (sim, None):
+        ld, tot = g(logits).clone(), torch.zeros(1, device=DEV)
+        lr2, totr = logits.clone(), torch.zeros(1)
+        lb = ops.keyword_ce_sim_(ld, g(kw_idx), g(kw_mask), g(sm), 0.01 / Bg, 1.0 / Bg, tot)
+        lbr = ref.keyword_ce_sim_(lr2, kw_idx, kw_mask, sm, 0.01 / Bg, 1.0 / Bg, totr)
+        close(lb, lbr, 1e-5, 1e-5, 'keyword CE loss')
+        close(ld, lr2, 1e-5, 1e-9, 'keyword CE dlogits')
+        close(tot, totr, 1e-5, 1e-6, 'keyword CE weighted loss sum')
+
+
+def test_adam_flat_matches_torch_adam(ops):
+    """gzsl_adam_flat_step against torch.optim.Adam(betas=(0.5, 0.999)) over 7 steps (bias correction from the
+    device-side step counter), n not a multiple of 4."""
+    rs = np.random.RandomState(3)
+    n = 64 * 1000 + 64
+    p0 = rnd(rs, n)
+    grads = [rnd(rs, n, scale=10.0 ** rs.uniform(-4, 0)) for _ in range(7)]
+    pt = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.5, 0.999))
+    p, m, v = g(p0).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    for i, gr in enumerate(grads):
+        pt.grad = gr.double()
+        opt.step()
+        ops.adam_flat_step_(p, g(gr), m, v, state, 1e-3, 0.5, 0.999, 1e-8)
+        assert state.tolist() == [i + 1, 0]
+    close(p, pt.detach().float(), 1e-6, 2e-7, 'parameters after 7 Adam steps (fp64 torch reference)')
+
+
 def test_gemm_random_shapes_and_views(ops, ref):
     """Random shapes, transposes, column slices (ldc > N, unaligned bases) and split-K sizes: every vector / scalar /
     fast / masked path of the GEMM against torch."""
