@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256) void keyword_ce_kernel(float* __restrict__ log
                                                          float* __restrict__ loss_b, int Bg, int Vk, int top_k,
                                                          int sim_mode, float grad_scale, float loss_scale, float* loss_sum) {
     __shared__ float red[4];
-    __shared__ float bcast;
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     float* lg = logits + (long long)row * Vk;
@@ -185,27 +184,38 @@ __global__ __launch_bounds__(256) void keyword_ce_kernel(float* __restrict__ log
     __syncthreads();
     se = red[0] + red[1] + red[2] + red[3];
     const float lse = mx + logf(se);
-    // targets: normalised mask, assignment semantics -> slot j is live iff no later slot repeats its index
-    float msum = 0.f;
-    for (int j = 0; j < top_k; ++j) msum += kw_mask[(long long)row * top_k + j];
-    const float inv = 1.f / (msum + 1e-7f);
-    float tsum = 0.f, lsum = 0.f;
-    if (tid == 0) {
-        for (int j = 0; j < top_k; ++j) {
-            const int64_t id = kw_idx[(long long)row * top_k + j];
-            bool live = true;
-            for (int j2 = j + 1; j2 < top_k; ++j2) live = live && (kw_idx[(long long)row * top_k + j2] != id);
-            if (live) {
-                const float t = kw_mask[(long long)row * top_k + j] * inv;
-                tsum += t;
-                lsum -= (lg[id] - lse) * t;
-            }
-        }
-        loss_b[row] = lsum;
-        bcast = tsum;
+    // targets: normalised mask, assignment semantics -> slot j is live iff no later slot repeats its index.  The row's
+    // top_k (index, mask) pairs are staged in LDS and the slots are worked on in parallel.
+    extern __shared__ __align__(16) char kw_smem[];
+    int64_t* s_idx = reinterpret_cast<int64_t*>(kw_smem);
+    float* s_t = reinterpret_cast<float*>(s_idx + top_k);  // mask, then target weight t_j (0 for dead slots)
+    float* s_l = s_t + top_k;                               // -(log_softmax at idx_j) * t_j
+    for (int j = tid; j < top_k; j += blockDim.x) {
+        s_idx[j] = kw_idx[(long long)row * top_k + j];
+        s_t[j] = kw_mask[(long long)row * top_k + j];
     }
-    __syncthreads();  // thread 0 has read its lg[id] before anybody overwrites the row
-    tsum = bcast;
+    __syncthreads();
+    float msum = 0.f;
+    for (int j = 0; j < top_k; ++j) msum += s_t[j];
+    const float inv = 1.f / (msum + 1e-7f);
+    __syncthreads();
+    for (int j = tid; j < top_k; j += blockDim.x) {
+        const int64_t id = s_idx[j];
+        bool live = true;
+        for (int j2 = j + 1; j2 < top_k; ++j2) live = live && (s_idx[j2] != id);
+        const float t = live ? s_t[j] * inv : 0.f;
+        s_l[j] = live ? -(lg[id] - lse) * t : 0.f;
+        s_t[j] = t;  // only slot j's owner reads the mask s_t[j] after the barrier above
+    }
+    __syncthreads();
+    float tsum = 0.f;
+    for (int j = 0; j < top_k; ++j) tsum += s_t[j];
+    float lsum = 0.f;
+    if (tid == 0) {
+        for (int j = 0; j < top_k; ++j) lsum += s_l[j];
+        loss_b[row] = lsum;
+    }
+    __syncthreads();  // every lg[id] above is read before anybody overwrites the row
     // sim_mode (train_gan.py:288-296): keywords_weight = sim.masked_fill(sim != 1, 0); the row's gradient weight is
     // keywords_weight * grad_scale and *loss_sum += loss_b * keywords_weight * loss_scale
     float wb = w ? w[row] : 1.f;
@@ -225,14 +235,8 @@ __global__ __launch_bounds__(256) void keyword_ce_kernel(float* __restrict__ log
         for (int v = tid; v < Vk; v += blockDim.x) lg[v] = wb * expf(lg[v] - lse) * tsum;
     }
     __syncthreads();
-    if (tid == 0) {
-        for (int j = 0; j < top_k; ++j) {
-            const int64_t id = kw_idx[(long long)row * top_k + j];
-            bool live = true;
-            for (int j2 = j + 1; j2 < top_k; ++j2) live = live && (kw_idx[(long long)row * top_k + j2] != id);
-            if (live) lg[id] -= wb * kw_mask[(long long)row * top_k + j] * inv;
-        }
-    }
+    for (int j = tid; j < top_k; j += blockDim.x)
+        if (s_t[j] != 0.f) lg[s_idx[j]] -= wb * s_t[j];  // live slots have distinct indices
 }
 
 // ---- whole-iteration kernels of the WGAN-GP step engine (gzsl_text_amd/gan_engine.py) --------------------------------
@@ -266,7 +270,12 @@ __device__ __forceinline__ void stv(float* p, const VecF<V>& r) {
     }
 }
 
-#define HEAD_RB 16  // rows per row block
+// Rows per row block and waves per workgroup: 16 rows x 4 waves for small batches; 64 rows x 16 waves from 1024 rows on
+// (same rows per wave, a quarter of the per-column atomics: 4096 rows x 800 columns would otherwise queue 256 atomics on
+// every column).
+#define HEAD_MAXW 16
+static inline int head_rb(int Bg) { return Bg >= 1024 ? 64 : 16; }
+static inline int head_threads(int Bg) { return Bg >= 1024 ? 1024 : 256; }
 
 // Critic iteration, everything between the fc1 GEMMs and the gradient GEMMs (train_gan.py:244-256 +
 // generative_module.py:22-38, closed form):
@@ -279,17 +288,17 @@ __device__ __forceinline__ void stv(float* p, const VecF<V>& r) {
 //   dw2 += sum_b wb (lrelu(h_fake) - lrelu(h_real));  d fc2.bias is exactly -sum wb + sum wb = 0 (the reference's
 //   autograd gives 0.0 too) and is left untouched;  cost += critic_fake - critic_real (fc2.bias cancels).
 template <int V>
-__global__ __launch_bounds__(256) void critic_head_kernel(const float* __restrict__ hf, const float* __restrict__ lh,
+__global__ __launch_bounds__(1024) void critic_head_kernel(const float* __restrict__ hf, const float* __restrict__ lh,
                                                           const float* __restrict__ w2, const float* __restrict__ sim,
                                                           const float* __restrict__ alpha, float* __restrict__ lst,
                                                           float* __restrict__ dhs, float* __restrict__ sl, float* dw2,
-                                                          float* cost, int Bg, int H) {
-    __shared__ float red[4][64 * V];
-    __shared__ float redc[4];
+                                                          float* cost, int Bg, int H, int rb) {
+    __shared__ float red[HEAD_MAXW][64 * V];
+    __shared__ float redc[HEAD_MAXW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * V;
     const bool live = col < H;
-    const int r0 = blockIdx.y * HEAD_RB, r1 = min(Bg, r0 + HEAD_RB);
+    const int r0 = blockIdx.y * rb, r1 = min(Bg, r0 + rb), nw = blockDim.x >> 6;
     const float inv_bg = 1.f / (float)Bg;
     VecF<V> w, acc;
 #pragma unroll
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256) void critic_head_kernel(const float* __restric
     if (live) w = ldv<V>(w2 + col);
     float c = 0.f;
     if (live) {
-        for (int r = r0 + wv; r < r1; r += 4) {
+        for (int r = r0 + wv; r < r1; r += nw) {
             const float wb = (sim ? sim[r] : 1.f) * inv_bg, a = alpha[r];
             const long long o = (long long)r * H + col;
             const VecF<V> l = ldv<V>(lh + o), fr = ldv<V>(hf + o), fk = ldv<V>(hf + (long long)Bg * H + o);
@@ -333,31 +342,37 @@ __global__ __launch_bounds__(256) void critic_head_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int k = lane * V + i;
-            atomicAdd(dw2 + col + i, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+            float t = 0.f;
+            for (int u = 0; u < nw; ++u) t += red[u][k];
+            atomicAdd(dw2 + col + i, t);
         }
     }
-    if (threadIdx.x == 0) atomicAdd(cost, redc[0] + redc[1] + redc[2] + redc[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int u = 0; u < nw; ++u) t += redc[u];
+        atomicAdd(cost, t);
+    }
 }
 
 // Generator iteration (train_gan.py:299-306): the critic is frozen, only d(-critic_fake)/dh is needed.
 //   h = hf + lh;  dh = -wb * w2 * s(h);  cost += -sum_b wb (lrelu(h_b) . w2 + b2)
 template <int V>
-__global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__ hf, const float* __restrict__ lh,
+__global__ __launch_bounds__(1024) void gen_head_kernel(const float* __restrict__ hf, const float* __restrict__ lh,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        const float* __restrict__ sim, float* __restrict__ dh, float* cost,
-                                                       int Bg, int H) {
-    __shared__ float redc[4];
+                                                       int Bg, int H, int rb) {
+    __shared__ float redc[HEAD_MAXW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * V;
     const bool live = col < H;
-    const int r0 = blockIdx.y * HEAD_RB, r1 = min(Bg, r0 + HEAD_RB);
+    const int r0 = blockIdx.y * rb, r1 = min(Bg, r0 + rb), nw = blockDim.x >> 6;
     const float inv_bg = 1.f / (float)Bg;
     VecF<V> w;
 #pragma unroll
     for (int i = 0; i < V; ++i) w.v[i] = 0.f;
     if (live) w = ldv<V>(w2 + col);
     float c = 0.f;
-    for (int r = r0 + wv; r < r1; r += 4) {
+    for (int r = r0 + wv; r < r1; r += nw) {
         const float wb = (sim ? sim[r] : 1.f) * inv_bg;
         if (blockIdx.x == 0 && lane == 0) c -= wb * b2[0];
         if (!live) continue;
@@ -375,23 +390,27 @@ __global__ __launch_bounds__(256) void gen_head_kernel(const float* __restrict__
     c = wave_sum(c);
     if (lane == 0) redc[wv] = c;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(cost, redc[0] + redc[1] + redc[2] + redc[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int u = 0; u < nw; ++u) t += redc[u];
+        atomicAdd(cost, t);
+    }
 }
 
 // dw2[j] += sum_b dv[b,j] * s[b,j] with the column-owner layout of the head kernels
 template <int V>
-__global__ __launch_bounds__(256) void gp_dw2_cols_kernel(const float* __restrict__ dv, const float* __restrict__ s,
-                                                          float* dw2, int Bg, int H) {
-    __shared__ float red[4][64 * V];
+__global__ __launch_bounds__(1024) void gp_dw2_cols_kernel(const float* __restrict__ dv, const float* __restrict__ s,
+                                                          float* dw2, int Bg, int H, int rb) {
+    __shared__ float red[HEAD_MAXW][64 * V];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = (blockIdx.x * 64 + lane) * V;
     const bool live = col < H;
-    const int r0 = blockIdx.y * HEAD_RB, r1 = min(Bg, r0 + HEAD_RB);
+    const int r0 = blockIdx.y * rb, r1 = min(Bg, r0 + rb), nw = blockDim.x >> 6;
     VecF<V> acc;
 #pragma unroll
     for (int i = 0; i < V; ++i) acc.v[i] = 0.f;
     if (live) {
-        for (int r = r0 + wv; r < r1; r += 4) {
+        for (int r = r0 + wv; r < r1; r += nw) {
             const long long o = (long long)r * H + col;
             const VecF<V> a = ldv<V>(dv + o), b = ldv<V>(s + o);
 #pragma unroll
@@ -405,21 +424,25 @@ __global__ __launch_bounds__(256) void gp_dw2_cols_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int k = lane * V + i;
-            atomicAdd(dw2 + col + i, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+            float t = 0.f;
+            for (int u = 0; u < nw; ++u) t += red[u][k];
+            atomicAdd(dw2 + col + i, t);
         }
     }
 }
 
 // torch.optim.Adam (no weight decay, no amsgrad) over a FLAT parameter buffer; the step counter lives on the device so
-// that a recorded HIP graph replays correctly.  state[0] = steps taken, state[1] = ticket counter: every workgroup
-// reads the step count before it takes its ticket, the last one to finish publishes step + 1 and resets the tickets.
+// that a recorded HIP graph replays correctly.  Every workgroup keeps its OWN copy of the count in state[blockIdx.x]
+// (the grid of a given buffer never changes), so there is no cross-workgroup ordering to establish: no atomics, no fences.
 //   m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#define ADAM_MAX_BLOCKS 1024
 __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long long n, float lr,
                                                         float b1, float b2, float eps, int* state) {
     __shared__ float sh[2];
     if (threadIdx.x == 0) {
-        const int t = *(volatile int*)state + 1;
+        const int t = state[blockIdx.x] + 1;
+        state[blockIdx.x] = t;
         const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
         sh[0] = (float)((double)lr / bc1);
         sh[1] = (float)sqrt(bc2);
@@ -448,17 +471,6 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
             m[i] = mm, v[i] = vv;
             p[i] -= step_size * (mm / (sqrtf(vv) / bc2_sqrt + eps));
         }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const int ticket = atomicAdd(state + 1, 1);
-        if (ticket == (int)gridDim.x - 1) {
-            const int t = *(volatile int*)state + 1;
-            *(volatile int*)state = t;
-            *(volatile int*)(state + 1) = 0;
-            __threadfence();
-        }
-    }
 }
 
 extern "C" int gzsl_gan_critic_head(const float* hf, const float* lh, const float* w2, const float* sim,
@@ -466,11 +478,12 @@ extern "C" int gzsl_gan_critic_head(const float* hf, const float* lh, const floa
                                     int H, void* stream) {
     if (Bg <= 0 || H <= 0) return 0;
     const bool v4 = (H & 3) == 0 && al16(hf) && al16(lh) && al16(w2) && al16(lst) && al16(dhs) && al16(sl);
-    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, HEAD_RB)), block(256);
+    const int rb = head_rb(Bg);
+    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, rb)), block(head_threads(Bg));
     if (v4)
-        hipLaunchKernelGGL(critic_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H);
+        hipLaunchKernelGGL(critic_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H, rb);
     else
-        hipLaunchKernelGGL(critic_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H);
+        hipLaunchKernelGGL(critic_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H, rb);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
@@ -479,9 +492,10 @@ extern "C" int gzsl_gan_gen_head(const float* hf, const float* lh, const float* 
                                  float* dh, float* cost, int Bg, int H, void* stream) {
     if (Bg <= 0 || H <= 0) return 0;
     const bool v4 = (H & 3) == 0 && al16(hf) && al16(lh) && al16(w2) && al16(dh);
-    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, HEAD_RB)), block(256);
-    if (v4) hipLaunchKernelGGL(gen_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, b2, sim, dh, cost, Bg, H);
-    else hipLaunchKernelGGL(gen_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, b2, sim, dh, cost, Bg, H);
+    const int rb = head_rb(Bg);
+    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, rb)), block(head_threads(Bg));
+    if (v4) hipLaunchKernelGGL(gen_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, b2, sim, dh, cost, Bg, H, rb);
+    else hipLaunchKernelGGL(gen_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, b2, sim, dh, cost, Bg, H, rb);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
@@ -490,8 +504,8 @@ extern "C" int gzsl_adam_flat_step(float* p, const float* g, float* m, float* v,
                                    float beta2, float eps, int* state, void* stream) {
     if (n <= 0) return 0;
     if (!al16(p) || !al16(g) || !al16(m) || !al16(v)) return GZSL_EINVAL;
-    long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    long long blocks = (n / 4 + 255) / 256;  // a function of n alone: the per-workgroup counters rely on it
+    if (blocks > ADAM_MAX_BLOCKS) blocks = ADAM_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_flat_kernel, dim3((int)blocks), dim3(256), 0, ST, p, g, m, v, n, lr, beta1, beta2, eps, state);
     GZSL_CHECK_LAUNCH();
@@ -526,9 +540,10 @@ extern "C" int gzsl_gp_rownorm(float* g, float* gp, int Bg, int D, float lam, vo
 extern "C" int gzsl_gp_dw2(const float* dv, const float* s, float* dw2, int Bg, int H, void* stream) {
     if (Bg <= 0) return 0;
     const bool v4 = (H & 3) == 0 && al16(dv) && al16(s);
-    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, HEAD_RB)), block(256);
-    if (v4) hipLaunchKernelGGL(gp_dw2_cols_kernel<4>, grid, block, 0, ST, dv, s, dw2, Bg, H);
-    else hipLaunchKernelGGL(gp_dw2_cols_kernel<1>, grid, block, 0, ST, dv, s, dw2, Bg, H);
+    const int rb = head_rb(Bg);
+    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, rb)), block(head_threads(Bg));
+    if (v4) hipLaunchKernelGGL(gp_dw2_cols_kernel<4>, grid, block, 0, ST, dv, s, dw2, Bg, H, rb);
+    else hipLaunchKernelGGL(gp_dw2_cols_kernel<1>, grid, block, 0, ST, dv, s, dw2, Bg, H, rb);
     GZSL_CHECK_LAUNCH();
     return 0;
 }
@@ -564,12 +579,13 @@ static int keyword_ce_launch(float* logits, const int64_t* kw_idx, const float* 
                              int Bg, int Vk, int top_k, int sim_mode, float grad_scale, float loss_scale, float* loss_sum,
                              void* stream) {
     if (Bg <= 0) return 0;
-    if (Vk <= 0 || top_k <= 0) return GZSL_EINVAL;
+    if (Vk <= 0 || top_k <= 0 || top_k > 2048) return GZSL_EINVAL;
+    const size_t smem = (size_t)top_k * 16;
     if ((Vk & 3) == 0 && Vk <= 8192 && al16(logits))
-        hipLaunchKernelGGL(keyword_ce_kernel<true>, dim3(Bg), dim3(256), 0, ST, logits, kw_idx, kw_mask, w, loss_b, Bg, Vk,
+        hipLaunchKernelGGL(keyword_ce_kernel<true>, dim3(Bg), dim3(256), smem, ST, logits, kw_idx, kw_mask, w, loss_b, Bg, Vk,
                            top_k, sim_mode, grad_scale, loss_scale, loss_sum);
     else
-        hipLaunchKernelGGL(keyword_ce_kernel<false>, dim3(Bg), dim3(256), 0, ST, logits, kw_idx, kw_mask, w, loss_b, Bg, Vk,
+        hipLaunchKernelGGL(keyword_ce_kernel<false>, dim3(Bg), dim3(256), smem, ST, logits, kw_idx, kw_mask, w, loss_b, Bg, Vk,
                            top_k, sim_mode, grad_scale, loss_scale, loss_sum);
     GZSL_CHECK_LAUNCH();
     return 0;

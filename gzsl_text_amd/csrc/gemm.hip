@@ -454,13 +454,15 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
 
 // ---- skinny GEMM: M <= 32 rows (the WGAN-GP step at the drivers' default batch of 8, train_gan.py:223-308) --------------
 // The tiled kernel above gives such a product to a handful of workgroups that each walk all of K behind one barrier per
-// 16 k (25-40 us for 8 x 800 x 800).  Here every workgroup owns 16 output columns, its four waves split K between
+// 16 k (25-40 us for 8 x 800 x 800).  Here every workgroup owns 16 output columns, its eight waves split K between
 // them, and the operands go straight from global memory into MFMA fragments (a lane's 16-byte load = its k values of
 // four consecutive steps: k = 16*group + 4*quarter + step, the same free choice of k order as everywhere else) -- no
-// LDS staging, no barrier in the loop; the four partial tiles meet in LDS once at the end.
+// LDS staging, no barrier in the loop; the partial tiles meet in LDS once at the end.
+#define SK_WAVES 8   // waves per workgroup, K interleaved over them in 16-k groups
+#define SK_UNROLL 4  // groups a wave has in flight: all their loads are issued before the first MFMA
 template <int MT, bool BKC, bool VEC>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GzslGemm g) {
-    __shared__ float red[4][MT][256];
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GzslGemm g) {
+    __shared__ float red[SK_WAVES][MT][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int n = n0 + lr;
@@ -478,51 +480,57 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GzslGemm g) {
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ngroups = (g.K + 15) / 16;
-#pragma unroll 4
-    for (int gi = wave; gi < ngroups; gi += 4) {
-        const int k0 = 16 * gi + 4 * lq;
-        float a[MT][4], b[4];
-        if (VEC) {  // K % 4 == 0: the lane's four k are all inside K or all outside
-            const bool k_ok = k0 < g.K;
-            const int kc = k_ok ? k0 : 0;
+    for (int gi0 = wave; gi0 < ngroups; gi0 += SK_WAVES * SK_UNROLL) {
+        float a[SK_UNROLL][MT][4], b[SK_UNROLL][4];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(arow[t] + kc);
-                const float keep = (a_ok[t] && k_ok) ? 1.f : 0.f;
+        for (int u = 0; u < SK_UNROLL; ++u) {
+            const int k0 = 16 * (gi0 + u * SK_WAVES) + 4 * lq;  // groups past the end read as zeros (k_ok false)
+            if (VEC) {  // K % 4 == 0: the lane's four k are all inside K or all outside
+                const bool k_ok = k0 < g.K;
+                const int kc = k_ok ? k0 : 0;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) a[t][s] = v[s] * keep;
-            }
-            const float keepb = (n_ok && k_ok) ? 1.f : 0.f;
-            if (BKC) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(bp + kc);
+                for (int t = 0; t < MT; ++t) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(arow[t] + kc);
+                    const float keep = (a_ok[t] && k_ok) ? 1.f : 0.f;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[s] = v[s] * keepb;
+                    for (int s = 0; s < 4; ++s) a[u][t][s] = v[s] * keep;
+                }
+                const float keepb = (n_ok && k_ok) ? 1.f : 0.f;
+                if (BKC) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(bp + kc);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[u][s] = v[s] * keepb;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[u][s] = bp[(long long)(kc + s) * g.b_sk] * keepb;
+                }
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[s] = bp[(long long)(kc + s) * g.b_sk] * keepb;
-            }
-        } else {
+                for (int s = 0; s < 4; ++s) {
+                    const bool k_ok = k0 + s < g.K;
+                    const int kc = k_ok ? k0 + s : 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bool k_ok = k0 + s < g.K;
-                const int kc = k_ok ? k0 + s : 0;
-#pragma unroll
-                for (int t = 0; t < MT; ++t) a[t][s] = arow[t][(long long)kc * g.a_sk] * ((a_ok[t] && k_ok) ? 1.f : 0.f);
-                b[s] = bp[(long long)kc * g.b_sk] * ((n_ok && k_ok) ? 1.f : 0.f);
+                    for (int t = 0; t < MT; ++t)
+                        a[u][t][s] = arow[t][(long long)kc * g.a_sk] * ((a_ok[t] && k_ok) ? 1.f : 0.f);
+                    b[u][s] = bp[(long long)kc * g.b_sk] * ((n_ok && k_ok) ? 1.f : 0.f);
+                }
             }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int u = 0; u < SK_UNROLL; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = mfma16(a[t][s], b[s], acc[t]);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = mfma16(a[u][t][s], b[u][s], acc[t]);
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][t][lane * 4 + r] = acc[t][r];
     __syncthreads();
-    // thread tid finishes accumulator element (lane' = tid >> 2, r = tid & 3) of every row tile: row 4*(lane' >> 4) + r,
-    // column lane' & 15; the four waves' partial sums are added in a fixed order
+    // thread tid < 256 finishes accumulator element (lane' = tid >> 2, r = tid & 3) of every row tile: row
+    // 4*(lane' >> 4) + r, column lane' & 15; the waves' partial sums are added in a fixed order
+    if (tid >= 256) return;
     const int ln = tid >> 2, r = tid & 3;
     const int col = n0 + (ln & 15);
     if (col >= g.N) return;
@@ -531,7 +539,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GzslGemm g) {
     for (int t = 0; t < MT; ++t) {
         const int row = 16 * t + 4 * (ln >> 4) + r;
         if (row >= g.M) continue;
-        float v = g.alpha * (red[0][t][tid] + red[1][t][tid] + red[2][t][tid] + red[3][t][tid]) + bv;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) sum += red[w][t][tid];
+        float v = g.alpha * sum + bv;
         float* cp = g.C + (long long)row * g.ldc + col;
         if (g.accumulate) v += *cp;
         if (g.act == GZSL_ACT_RELU) v = fmaxf(v, 0.f);
@@ -545,7 +556,7 @@ static int launch_skinny(const GzslGemm& g, hipStream_t st) {
     const bool bkc = g.b_sk == 1;
     const bool vec = g.a_sk == 1 && (g.K & 3) == 0 && (g.a_sm & 3) == 0 && ((uintptr_t)g.A & 15) == 0 &&
                      (!bkc || ((g.b_sn & 3) == 0 && ((uintptr_t)g.B & 15) == 0));
-    const dim3 grid(cdiv(g.N, 16)), block(256);
+    const dim3 grid(cdiv(g.N, 16)), block(64 * SK_WAVES);
 #define GZ_SK(MT, KC, V) hipLaunchKernelGGL((gemm_skinny_kernel<MT, KC, V>), grid, block, 0, st, g)
 #define GZ_SK2(MT)                             \
     do {                                       \

@@ -257,7 +257,8 @@ class WganGpStep:
             self.kw['word_emb'] = kw['word_emb']
         self._opt = {}
         for name, p in (('d', self._pd), ('g', self._pg)):
-            self._opt[name] = (torch.zeros_like(p), torch.zeros_like(p), torch.zeros(2, dtype=torch.int32, device=dev))
+            self._opt[name] = (torch.zeros_like(p), torch.zeros_like(p),
+                               torch.zeros(ops.ADAM_STATE_INTS, dtype=torch.int32, device=dev))
 
     @staticmethod
     def _rehome(layout, src, dev):

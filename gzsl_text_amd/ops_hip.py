@@ -429,9 +429,13 @@ class HipOps:
         call('gzsl_gan_gen_head', ptr(hf), ptr(lh), ptr(w2), ptr(b2), ptr(sim), ptr(dh), ptr(cost), Bg, H)
         return dh
 
+    ADAM_STATE_INTS = 1024  # GZSL_ADAM_STATE_INTS
+
     def adam_flat_step_(self, p, g, m, v, state, lr, beta1, beta2, eps):
-        """torch.optim.Adam.step over one flat buffer; `state` = int32 [2] on the device (step count, ticket)."""
-        assert p.numel() == g.numel() == m.numel() == v.numel() and state.dtype == torch.int32 and state.numel() == 2
+        """torch.optim.Adam.step over one flat buffer; `state` = int32 [ADAM_STATE_INTS] on the device, zero before the
+        first step (per-workgroup copies of the step count; state[0] = steps taken)."""
+        assert p.numel() == g.numel() == m.numel() == v.numel()
+        assert state.dtype == torch.int32 and state.numel() == self.ADAM_STATE_INTS
         call('gzsl_adam_flat_step', ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, ptr(state))
 
     def keyword_ce_sim_(self, logits, kw_idx, kw_mask, sim, grad_scale, loss_scale, loss_sum):

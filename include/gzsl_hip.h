@@ -216,9 +216,11 @@ int gzsl_gan_gen_head(const float* hf, const float* lh, const float* w2, const f
                       float* cost, int Bg, int H, void* stream);
 /* torch.optim.Adam.step (train_gan.py:155-157: betas (0.5, 0.999), no weight decay, no amsgrad) over ONE flat buffer of
  * n parameters (16-byte aligned): m += (g-m)(1-beta1); v = beta2 v + (1-beta2) g^2;
- * p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps).  state [2] int32, zero before the first step: state[0] =
- * steps taken (read, then incremented by the last workgroup to finish), state[1] = ticket counter.  The step count
- * lives on the device so that a recorded HIP graph replays with the right bias correction. */
+ * p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps).  state: GZSL_ADAM_STATE_INTS int32, zero before the first
+ * step and owned by (p, n) from then on: every workgroup keeps its own copy of the step count there (all equal between
+ * calls; state[0] is the number of steps taken).  The count lives on the device so that a recorded HIP graph replays
+ * with the right bias correction; private copies mean no atomics and no ordering between workgroups. */
+#define GZSL_ADAM_STATE_INTS 1024
 int gzsl_adam_flat_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                         float eps, int* state, void* stream);
 

@@ -306,9 +306,11 @@ class CpuOps:
         cost -= (wb * (F.leaky_relu(h, 0.2) @ w2 + b2[0])).sum()
         return -wb[:, None] * w2[None] * torch.where(h > 0, torch.ones_like(h), torch.full_like(h, 0.2))
 
+    ADAM_STATE_INTS = 1024
+
     def adam_flat_step_(self, p, g, m, v, state, lr, beta1, beta2, eps):
         t = int(state[0]) + 1
-        state[0] = t
+        state += 1
         m.add_((g - m) * (1 - beta1))
         v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
         p.sub_((lr / (1 - beta1 ** t)) * m / (v.sqrt() / (1 - beta2 ** t) ** 0.5 + eps))

@@ -412,12 +412,13 @@ def test_adam_flat_matches_torch_adam(ops):
     pt = torch.nn.Parameter(p0.clone().double())
     opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.5, 0.999))
     p, m, v = g(p0).clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    state = torch.zeros(2, dtype=torch.int32, device=DEV)
+    state = torch.zeros(ops.ADAM_STATE_INTS, dtype=torch.int32, device=DEV)
     for i, gr in enumerate(grads):
         pt.grad = gr.double()
         opt.step()
         ops.adam_flat_step_(p, g(gr), m, v, state, 1e-3, 0.5, 0.999, 1e-8)
-        assert state.tolist() == [i + 1, 0]
+        nblk = min(1024, (n // 4 + 255) // 256)
+        assert state[:nblk].eq(i + 1).all() and state[nblk:].eq(0).all()
     close(p, pt.detach().float(), 1e-6, 2e-7, 'parameters after 7 Adam steps (fp64 torch reference)')
 
 
