@@ -284,7 +284,7 @@ static inline int head_threads(int Bg) { return Bg >= 1024 ? 1024 : 256; }
 //   lst rows [0,Bg)    = d(-critic_real)/dh_real = -wb * w2 * s(h_real)
 //       rows [Bg,2Bg)  = d(+critic_fake)/dh_fake = +wb * w2 * s(h_fake)
 //       rows [2Bg,3Bg) = v = s(h_hat) * w2,  h_hat = alpha h_real + (1 - alpha) h_fake   (fc1 is affine: no third GEMM)
-//   dhs = lst[real] + lst[fake] (label half / bias gradient), sl = s(h_hat)
+//   dhs = lst[real] + lst[fake] (label half / bias gradient), db1 += column sums of dhs (d fc1.bias), sl = s(h_hat)
 //   dw2 += sum_b wb (lrelu(h_fake) - lrelu(h_real));  d fc2.bias is exactly -sum wb + sum wb = 0 (the reference's
 //   autograd gives 0.0 too) and is left untouched;  cost += critic_fake - critic_real (fc2.bias cancels).
 template <int V>
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(1024) void critic_head_kernel(const float* __restri
                                                           const float* __restrict__ w2, const float* __restrict__ sim,
                                                           const float* __restrict__ alpha, float* __restrict__ lst,
                                                           float* __restrict__ dhs, float* __restrict__ sl, float* dw2,
-                                                          float* cost, int Bg, int H, int rb) {
+                                                           float* db1, float* cost, int Bg, int H, int rb) {
     __shared__ float red[HEAD_MAXW][64 * V];
     __shared__ float redc[HEAD_MAXW];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -300,9 +300,9 @@ __global__ __launch_bounds__(1024) void critic_head_kernel(const float* __restri
     const bool live = col < H;
     const int r0 = blockIdx.y * rb, r1 = min(Bg, r0 + rb), nw = blockDim.x >> 6;
     const float inv_bg = 1.f / (float)Bg;
-    VecF<V> w, acc;
+    VecF<V> w, acc, accb;
 #pragma unroll
-    for (int i = 0; i < V; ++i) acc.v[i] = 0.f, w.v[i] = 0.f;
+    for (int i = 0; i < V; ++i) acc.v[i] = 0.f, accb.v[i] = 0.f, w.v[i] = 0.f;
     if (live) w = ldv<V>(w2 + col);
     float c = 0.f;
     if (live) {
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(1024) void critic_head_kernel(const float* __restri
                 ss.v[i] = sh;
                 const float diff = (hk > 0.f ? hk : 0.2f * hk) - (hr > 0.f ? hr : 0.2f * hr);
                 acc.v[i] += wb * diff;
+                accb.v[i] += ds.v[i];
                 c += wb * diff * w.v[i];
             }
             stv<V>(lst + o, dr);
@@ -351,6 +352,19 @@ __global__ __launch_bounds__(1024) void critic_head_kernel(const float* __restri
         float t = 0.f;
         for (int u = 0; u < nw; ++u) t += redc[u];
         atomicAdd(cost, t);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V; ++i) red[wv][lane * V + i] = accb.v[i];
+    __syncthreads();
+    if (wv == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int k = lane * V + i;
+            float t = 0.f;
+            for (int u = 0; u < nw; ++u) t += red[u][k];
+            atomicAdd(db1 + col + i, t);
+        }
     }
 }
 
@@ -474,16 +488,16 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
 }
 
 extern "C" int gzsl_gan_critic_head(const float* hf, const float* lh, const float* w2, const float* sim,
-                                    const float* alpha, float* lst, float* dhs, float* sl, float* dw2, float* cost, int Bg,
-                                    int H, void* stream) {
+                                    const float* alpha, float* lst, float* dhs, float* sl, float* dw2, float* db1,
+                                    float* cost, int Bg, int H, void* stream) {
     if (Bg <= 0 || H <= 0) return 0;
     const bool v4 = (H & 3) == 0 && al16(hf) && al16(lh) && al16(w2) && al16(lst) && al16(dhs) && al16(sl);
     const int rb = head_rb(Bg);
     const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, rb)), block(head_threads(Bg));
     if (v4)
-        hipLaunchKernelGGL(critic_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H, rb);
+        hipLaunchKernelGGL(critic_head_kernel<4>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, db1, cost, Bg, H, rb);
     else
-        hipLaunchKernelGGL(critic_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, cost, Bg, H, rb);
+        hipLaunchKernelGGL(critic_head_kernel<1>, grid, block, 0, ST, hf, lh, w2, sim, alpha, lst, dhs, sl, dw2, db1, cost, Bg, H, rb);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

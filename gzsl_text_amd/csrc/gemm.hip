@@ -479,14 +479,22 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GzslGemm g) 
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ngroups = (g.K + 15) / 16;
+    // split-K (long K, few columns): blockIdx.y owns k_per_split of K and stores its partial tile to slab blockIdx.y
+    int kbeg = 0, kend = g.K;
+    float* C = g.C;
+    if (g.split_k > 1) {
+        kbeg = blockIdx.y * g.k_per_split;
+        kend = min(g.K, kbeg + g.k_per_split);
+        C += (long long)blockIdx.y * g.slab_stride;
+    }
+    const int ngroups = (max(kend - kbeg, 0) + 15) / 16;
     for (int gi0 = wave; gi0 < ngroups; gi0 += SK_WAVES * SK_UNROLL) {
         float a[SK_UNROLL][MT][4], b[SK_UNROLL][4];
 #pragma unroll
         for (int u = 0; u < SK_UNROLL; ++u) {
-            const int k0 = 16 * (gi0 + u * SK_WAVES) + 4 * lq;  // groups past the end read as zeros (k_ok false)
-            if (VEC) {  // K % 4 == 0: the lane's four k are all inside K or all outside
-                const bool k_ok = k0 < g.K;
+            const int k0 = kbeg + 16 * (gi0 + u * SK_WAVES) + 4 * lq;  // groups past the end read as zeros (k_ok false)
+            if (VEC) {  // K, kbeg, kend % 4 == 0: the lane's four k are all inside the range or all outside
+                const bool k_ok = k0 < kend;
                 const int kc = k_ok ? k0 : 0;
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GzslGemm g) 
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const bool k_ok = k0 + s < g.K;
+                    const bool k_ok = k0 + s < kend;
                     const int kc = k_ok ? k0 + s : 0;
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GzslGemm g) 
 #pragma unroll
         for (int w = 0; w < SK_WAVES; ++w) sum += red[w][t][tid];
         float v = g.alpha * sum + bv;
-        float* cp = g.C + (long long)row * g.ldc + col;
+        float* cp = C + (long long)row * g.ldc + col;
         if (g.accumulate) v += *cp;
         if (g.act == GZSL_ACT_RELU) v = fmaxf(v, 0.f);
         else if (g.act == GZSL_ACT_TANH) v = tanhf(v);
@@ -556,7 +564,7 @@ static int launch_skinny(const GzslGemm& g, hipStream_t st) {
     const bool bkc = g.b_sk == 1;
     const bool vec = g.a_sk == 1 && (g.K & 3) == 0 && (g.a_sm & 3) == 0 && ((uintptr_t)g.A & 15) == 0 &&
                      (!bkc || ((g.b_sn & 3) == 0 && ((uintptr_t)g.B & 15) == 0));
-    const dim3 grid(cdiv(g.N, 16)), block(64 * SK_WAVES);
+    const dim3 grid(cdiv(g.N, 16), g.split_k > 1 ? g.split_k : 1), block(64 * SK_WAVES);
 #define GZ_SK(MT, KC, V) hipLaunchKernelGGL((gemm_skinny_kernel<MT, KC, V>), grid, block, 0, st, g)
 #define GZ_SK2(MT)                             \
     do {                                       \
@@ -571,6 +579,55 @@ static int launch_skinny(const GzslGemm& g, hipStream_t st) {
 #undef GZ_SK
     GZSL_CHECK_LAUNCH();
     return 0;
+}
+
+// ---- short-K outer-product GEMM: the weight gradients of the WGAN-GP step at small batches (K = Bg .. 3 Bg <= 64) -----
+// C[M,N] = alpha * A^T-stored(M,K) . B(K,N) (+ C), both operands contiguous along their rows (a_sm == 1, b_sn == 1).
+// With K this short the MFMA tile kernel is all prologue and epilogue (7 us for 800 x 400 x 24); here a thread owns a
+// 4 x 4 output block and reads its two float4 per k straight from global memory (L2-resident, 16 lanes share a row of B,
+// 4 lanes a row of A), every load independent of the FMAs.
+__global__ __launch_bounds__(256) void gemm_shortk_kernel(GzslGemm g) {
+    const int tid = threadIdx.x, tn = tid & 15, tm = tid >> 4;
+    const int m = blockIdx.x * 64 + 4 * tm, n = blockIdx.y * 64 + 4 * tn;
+    if (m >= g.M || n >= g.N) return;
+    const float* ap = g.A + m;
+    const float* bp = g.B + n;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= g.K; k += 8) {
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(ap + (long long)(k + u) * g.a_sk);
+            b[u] = *reinterpret_cast<const f32x4*>(bp + (long long)(k + u) * g.b_sk);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += a[u][i] * b[u];
+    }
+    for (; k < g.K; ++k) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + (long long)k * g.a_sk);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + (long long)k * g.b_sk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += a[i] * b;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4* cp = reinterpret_cast<f32x4*>(g.C + (long long)(m + i) * g.ldc + n);
+        f32x4 v = acc[i] * g.alpha;
+        if (g.accumulate) v += *cp;
+        *cp = v;
+    }
+}
+
+static bool shortk_ok(const GzslGemm& g) {
+    return g.K <= 64 && g.K >= 1 && g.split_k <= 1 && g.a_sm == 1 && g.b_sn == 1 && g.a_mb >= g.M && g.k_inner >= g.K &&
+           g.a_shift == 0 && g.a_span >= 0x7FFFFFFFu && !g.bias && g.act == GZSL_ACT_NONE && (g.M & 3) == 0 &&
+           (g.N & 3) == 0 && (g.a_sk & 3) == 0 && (g.b_sk & 3) == 0 && (g.ldc & 3) == 0 && ((uintptr_t)g.A & 15) == 0 &&
+           ((uintptr_t)g.B & 15) == 0 && ((uintptr_t)g.C & 15) == 0 && g.M >= 64 && g.N >= 64;
 }
 
 // out[m*ldo + n] (=|+=) act(sum_z slab[z*stride + m*N + n] + bias[n]);  optional conv-weight unpack:
@@ -685,9 +742,14 @@ extern "C" int gzsl_gemm(const GzslGemm* gp, void* stream) {
     }
     // few rows, plain operands: the skinny kernel (columns over workgroups, K over the waves of a workgroup)
     static const int no_skinny = env_int("GZSL_GEMM_NO_SKINNY", 0);
-    if (!no_skinny && g.M <= 32 && g.K >= 32 && g.split_k <= 1 && g.a_mb >= g.M && g.k_inner >= g.K && g.a_shift == 0 &&
+    if (!no_skinny && g.M <= 32 && g.K >= 32 && g.a_mb >= g.M && g.k_inner >= g.K && g.a_shift == 0 &&
         g.a_span >= 0x7FFFFFFFu)
         return launch_skinny(g, st);
+    if (!no_skinny && shortk_ok(g)) {  // K <= 64 outer products (GZSL_GEMM_NO_SKINNY=1 disables both special kernels)
+        hipLaunchKernelGGL(gemm_shortk_kernel, dim3(cdiv(g.M, 64), cdiv(g.N, 64)), dim3(256), 0, st, g);
+        GZSL_CHECK_LAUNCH();
+        return 0;
+    }
     // tile width: the one whose padded N wastes least MFMA work (ties -> wider tile) ...
     const int pad128 = cdiv(g.N, 128) * 128, pad208 = cdiv(g.N, 208) * 208, pad112 = cdiv(g.N, 112) * 112;
     int wn = (pad208 < pad128 && pad208 <= pad112) ? 13 : (pad112 < pad128 ? 7 : 8);

@@ -168,14 +168,14 @@ class GanEngine:
         self.generator_fwd(g, noise, lab, out=fake)
         lh = self.critic_label_half(d, lab, D)
         hf = ops.mm(F[:2 * Bg], W1f.t())
-        lst, dhs, sl = ops.gan_critic_head(hf, lh, w2, sim, alpha.reshape(-1), G['fc2.weight'][0], scal[0:1])
+        lst, dhs, sl = ops.gan_critic_head(hf, lh, w2, sim, alpha.reshape(-1), G['fc2.weight'][0], G['fc1.bias'],
+                                           scal[0:1])
         gvec = ops.mm(lst[2 * Bg:], W1f, out=F[2 * Bg:])
         ops.gp_rownorm_(gvec, lam, out=scal[1:2])  # gvec <- d gp / d gvec
         dv = ops.mm(gvec, W1f.t())
         ops.gp_dw2_(dv, sl, G['fc2.weight'][0])
         ops.mm(lst.t(), F, out=G['fc1.weight'][:, :D])
         ops.mm(dhs.t(), lab, out=G['fc1.weight'][:, D:])
-        ops.colsum(dhs, out=G['fc1.bias'])
         return scal[0], scal[1], G, fake
 
     def generator_iteration(self, d, g, kw, lab, noise, sim=None, kw_idx=None, kw_mask=None, reg_ratio=0.0):

@@ -71,7 +71,7 @@ _PROTOS = {
     'gzsl_rowdot_bwd': [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p],
     'gzsl_keyword_ce': [c_void_p] * 5 + [c_int] * 3 + [c_void_p],
     'gzsl_keyword_ce_sim': [c_void_p] * 4 + [c_float, c_float, c_void_p, c_void_p] + [c_int] * 3 + [c_void_p],
-    'gzsl_gan_critic_head': [c_void_p] * 10 + [c_int, c_int, c_void_p],
+    'gzsl_gan_critic_head': [c_void_p] * 11 + [c_int, c_int, c_void_p],
     'gzsl_gan_gen_head': [c_void_p] * 7 + [c_int, c_int, c_void_p],
     'gzsl_adam_flat_step': [c_void_p] * 4 + [c_ll] + [c_float] * 4 + [c_void_p, c_void_p],
 }

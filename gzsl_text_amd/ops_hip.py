@@ -46,6 +46,12 @@ class HipOps:
     def _split_policy(M, N, K):
         """Split K when the output has too few 64-row tiles to fill 256 CUs x 3 workgroups (weight gradients: small
         MxN, huge K).  Every split keeps at least 256 k (16 k-tiles) so that the prologue / epilogue stay amortised."""
+        if M <= 32:  # skinny kernel: 16 columns per workgroup; split a long K until ~256 workgroups, >= 512 k each
+            split = min(256 // ((N + 15) // 16), K // 512)
+            if split <= 1:
+                return 1, 0
+            kper = ((K + split - 1) // split + 31) // 32 * 32
+            return (K + kper - 1) // kper, kper
         bn = min((208, 112, 128), key=lambda w: ((N + w - 1) // w * w, -w))
         tiles = ((M + 63) // 64) * ((N + bn - 1) // bn)
         if tiles >= 384 or K < 1024:
@@ -412,14 +418,14 @@ class HipOps:
              int(lrelu_in))
         return da
 
-    def gan_critic_head(self, hf, lh, w2, sim, alpha, dw2, cost):
-        """gzsl_gan_critic_head: returns (lst [3Bg,H], dhs [Bg,H], sl [Bg,H]); dw2 / cost are accumulated."""
+    def gan_critic_head(self, hf, lh, w2, sim, alpha, dw2, db1, cost):
+        """gzsl_gan_critic_head: returns (lst [3Bg,H], dhs [Bg,H], sl [Bg,H]); dw2 / db1 / cost are accumulated."""
         Bg, H = lh.shape
         assert hf.shape == (2 * Bg, H) and alpha.numel() == Bg and (sim is None or sim.numel() == Bg)
         lst = torch.empty((3 * Bg, H), dtype=torch.float32, device=lh.device)
         dhs, sl = torch.empty_like(lh), torch.empty_like(lh)
         call('gzsl_gan_critic_head', ptr(hf), ptr(lh), ptr(w2), ptr(sim), ptr(alpha), ptr(lst), ptr(dhs), ptr(sl), ptr(dw2),
-             ptr(cost), Bg, H)
+             ptr(db1), ptr(cost), Bg, H)
         return lst, dhs, sl
 
     def gan_gen_head(self, hf, lh, w2, b2, sim, cost):

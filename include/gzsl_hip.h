@@ -206,10 +206,12 @@ int gzsl_keyword_ce_sim(float* logits, const int64_t* kw_idx, const float* kw_ma
  * fc1.weight[:, D:]^T + fc1.bias; pre-activations h = hf + lh; wb = sim[b]/Bg (sim NULL: 1/Bg); slope s in {1, 0.2}.
  *   lst [3Bg,H]: rows [0,Bg) = -wb*w2*s(h_real), [Bg,2Bg) = +wb*w2*s(h_fake), [2Bg,3Bg) = s(h_hat)*w2 with
  *   h_hat = alpha*h_real + (1-alpha)*h_fake;  dhs [Bg,H] = the first two row blocks added;  sl [Bg,H] = s(h_hat);
- *   dw2[j] += sum_b wb*(lrelu(h_fake) - lrelu(h_real))[b,j]   (atomic);   *cost += critic_fake - critic_real (atomic).
+ *   dw2[j] += sum_b wb*(lrelu(h_fake) - lrelu(h_real))[b,j];  db1[j] += sum_b dhs[b,j] (d fc1.bias);
+ *   *cost += critic_fake - critic_real   (all three through float atomics).
  * d fc2.bias of the critic objective is identically 0 and is not written. */
 int gzsl_gan_critic_head(const float* hf, const float* lh, const float* w2, const float* sim, const float* alpha,
-                         float* lst, float* dhs, float* sl, float* dw2, float* cost, int Bg, int H, void* stream);
+                         float* lst, float* dhs, float* sl, float* dw2, float* db1, float* cost, int Bg, int H,
+                         void* stream);
 /* Generator iteration (train_gan.py:299-306), critic frozen: dh[b,j] = -wb*w2[j]*s(h[b,j]), h = hf + lh [Bg,H];
  * *cost += -sum_b wb*(lrelu(h_b) . w2 + b2[0]) (atomic). */
 int gzsl_gan_gen_head(const float* hf, const float* lh, const float* w2, const float* b2, const float* sim, float* dh,

@@ -285,7 +285,7 @@ class CpuOps:
             return dout[:, None] * w[None, :] * torch.where(act > 0, torch.ones_like(act), torch.full_like(act, 0.2))
         return None
 
-    def gan_critic_head(self, hf, lh, w2, sim, alpha, dw2, cost):
+    def gan_critic_head(self, hf, lh, w2, sim, alpha, dw2, db1, cost):
         Bg, H = lh.shape
         wb = (torch.ones(Bg) if sim is None else sim) / Bg
         hr, hk = hf[:Bg] + lh, hf[Bg:] + lh
@@ -297,6 +297,7 @@ class CpuOps:
         diff = F.leaky_relu(hk, 0.2) - F.leaky_relu(hr, 0.2)
         dw2 += (wb[:, None] * diff).sum(0)
         cost += (wb[:, None] * diff * w2[None]).sum()
+        db1 += (dr + dk).sum(0)
         return torch.cat([dr, dk, slope(hh) * w2[None]], 0).contiguous(), (dr + dk).contiguous(), slope(hh)
 
     def gan_gen_head(self, hf, lh, w2, b2, sim, cost):

@@ -74,6 +74,34 @@ def test_gemm_skinny_rows(ops, ref, M, N, K):
         close(out, want, 2e-5, 2e-5 * np.sqrt(K), 'two K segments with LeakyReLU')
 
 
+@pytest.mark.parametrize('M,N,K', [(800, 400, 24), (800, 800, 8), (64, 64, 1), (132, 68, 64), (800, 400, 63)])
+def test_gemm_short_k_outer_products(ops, ref, M, N, K):
+    """K <= 64 with both operands row-contiguous (weight gradients dh^T @ x of the WGAN-GP step at small batches) takes
+    the short-K kernel: plain, alpha + accumulate, and a column block of a wider matrix as the output."""
+    rs = np.random.RandomState(M + N + K)
+    A, B = rnd(rs, K, M), rnd(rs, K, N)
+    close(ops.mm(g(A).t(), g(B)), A.t() @ B, 2e-5, 2e-5 * np.sqrt(K), 'A^T B')
+    big = rnd(rs, M, N + 100)
+    bigd = g(big).clone()
+    ops.mm(g(A).t(), g(B), out=bigd[:, 100:], accumulate=True, alpha=0.5)
+    big[:, 100:] += 0.5 * (A.t() @ B)
+    close(bigd, big, 2e-5, 2e-5 * np.sqrt(K), 'accumulate into a column block')
+
+
+@pytest.mark.parametrize('M,N,K', [(8, 200, 4096), (16, 400, 8192), (3, 37, 5000)])
+def test_gemm_skinny_split_k(ops, ref, M, N, K):
+    """Few rows, few columns, long K (keyword head: dlogits [Bg,Vk] @ word_emb [Vk,E]): the skinny kernel with K split
+    over blockIdx.y and the ordered slab reduce."""
+    rs = np.random.RandomState(M + N + K)
+    x, W, bias = rnd(rs, M, K), rnd(rs, K, N, scale=0.1), rnd(rs, N)
+    assert ops._split_policy(M, N, K)[0] > 1
+    close(ops.mm(g(x), g(W), bias=g(bias), act=3), torch.nn.functional.leaky_relu(x @ W + bias, 0.2), 2e-5,
+          2e-5 * np.sqrt(K), 'x @ W split-K')
+    C0 = rnd(rs, M, N)
+    close(ops.mm(g(x), g(W.t().contiguous()).t(), out=g(C0).clone(), accumulate=True), C0 + x @ W, 2e-5, 2e-5 * np.sqrt(K),
+          'x @ W^T split-K accumulate')
+
+
 def test_gemm_split_k_and_strided_output(ops, ref):
     rs = np.random.RandomState(5)
     M, N, K = 100, 200, 20000
@@ -366,13 +394,14 @@ def test_gan_iteration_kernels(ops, ref, Bg, H, D, Vk):
     sim = torch.from_numpy(rs.choice([1.0, 0.4, 0.0], size=Bg).astype(np.float32))
     alpha = torch.from_numpy(rs.random_sample(Bg).astype(np.float32))
     for sm in (sim, None):
-        dw2, cost = torch.zeros(H, device=DEV), torch.zeros(1, device=DEV)
-        dw2r, costr = torch.zeros(H), torch.zeros(1)
-        got = ops.gan_critic_head(g(hf), g(lh), g(w2), g(sm), g(alpha), dw2, cost)
-        want = ref.gan_critic_head(hf, lh, w2, sm, alpha, dw2r, costr)
+        dw2, db1, cost = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(1, device=DEV)
+        dw2r, db1r, costr = torch.zeros(H), torch.zeros(H), torch.zeros(1)
+        got = ops.gan_critic_head(g(hf), g(lh), g(w2), g(sm), g(alpha), dw2, db1, cost)
+        want = ref.gan_critic_head(hf, lh, w2, sm, alpha, dw2r, db1r, costr)
         for a, b, nm in zip(got, want, ('lst', 'dhs', 'slopes')):
             close(a, b, 1e-6, 1e-7, 'critic head ' + nm)
         close(dw2, dw2r, 1e-5, 2e-6, 'critic head dw2')
+        close(db1, db1r, 1e-5, 2e-6, 'critic head db1')
         close(cost, costr, 1e-4, 1e-5 * np.sqrt(H), 'critic head cost')
         cost, costr = torch.zeros(1, device=DEV), torch.zeros(1)
         close(ops.gan_gen_head(g(hf[:Bg]), g(lh), g(w2), g(b2), g(sm), cost), ref.gan_gen_head(hf[:Bg], lh, w2, b2, sm, costr),
