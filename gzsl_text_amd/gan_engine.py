@@ -5,12 +5,15 @@ Parameters are dicts keyed like the reference's state dicts:
   keyword head: proj_fc.weight [E, D], proj_fc.bias, word_emb [Vk, E] (frozen buffer)       (decoder_module.py:25-31)
 
 What differs from "run the reference's ops one by one":
-  * torch.cat([x, label]) is never formed: fc1 is two GEMMs over the column blocks of fc1.weight, the second
-    accumulating into the first's output with the activation in its epilogue.
   * The label half of the critic's fc1 (lab @ W1[:, D:]^T + b1) is shared by D(real), D(fake) and the penalty.
   * The gradient penalty uses the closed form (no double backward), and its fc1 pre-activation is the alpha-blend of
     the real / fake pre-activations (fc1 is affine and the label half is common), so it costs no extra fc1 GEMM.
-  * The critic's single-output fc2 is a fused row-dot with LeakyReLU applied on the fly.
+  * Building blocks used by the nn.Module mirrors (modules/generative_module.py, decoder_module.py): fc1 as two GEMMs
+    over the column blocks of fc1.weight (no torch.cat), the critic's single-output fc2 as a fused row-dot with
+    LeakyReLU applied on the fly.
+  * Whole iterations (`critic_iteration`, `generator_iteration`, what `WganGpStep` runs): rows are stacked so that every
+    product is one GEMM, everything between the GEMMs is one kernel, parameters / gradients / Adam moments live in flat
+    buffers with one layout (see the comment above `critic_iteration`).
 Sign conventions follow the driver: critic grads = d(-critic_real + critic_fake + gp), generator grads =
 d(-critic_fake + reg_ratio * keyword_loss) (train_gan.py:244-256, 300-306).
 """
@@ -61,19 +64,39 @@ def zero_grads(layout, device):
     return flat[:layout.size], layout.views(flat), flat[layout.size:]
 
 
+class _Transposed:
+    """W^T as the right-hand operand of `x @ W^T` for nn.Linear weights W [N, K].  The strided view W.t() makes the GEMM
+    read B along k (64-byte pieces of 208 weight rows per k-tile); from 8192 rows of x on, a materialised [K, N] copy
+    (B contiguous along its rows) is 15-28 % faster at the step's widths (tools/bench_gan_gemm.py: 16384 x 800 x 400 in
+    107 instead of 146 us) and the 6 us copy is paid back by the first product.  One copy per weight and iteration."""
+    RC_ROWS = 8192
+
+    def __init__(self):
+        self._t = {}
+
+    def __call__(self, W, rows, k0=0, k1=None):
+        """(W[:, k0:k1])^T for a product with `rows` rows on the left."""
+        if rows < self.RC_ROWS:
+            return W[:, k0:k1].t()
+        if id(W) not in self._t:
+            self._t[id(W)] = W.t().contiguous()
+        return self._t[id(W)][k0:k1]
+
+
 class GanEngine:
     def __init__(self, ops):
         self.ops = ops
 
     # ------------------------------------------------------------------------------------------ generator
-    def generator_fwd(self, g, noise, lab, relu_out=True, out=None):
+    def generator_fwd(self, g, noise, lab, relu_out=True, out=None, tr=None):
         """relu(G(noise, lab)) (generative_module.py:48-53 + train_gan.py:248).  Returns (fake, hidden activations)."""
         ops = self.ops
-        n1 = noise.shape[1]
+        tr = tr or _Transposed()
+        Bg, n1 = noise.shape
         W1 = g['fc1.weight']
-        h = ops.mm(noise, W1[:, :n1].t(), bias=g['fc1.bias'])
-        ops.mm(lab, W1[:, n1:].t(), out=h, accumulate=True, act=ACT_LRELU)
-        fake = ops.mm(h, g['fc2.weight'].t(), out=out, bias=g['fc2.bias'], act=ACT_RELU if relu_out else ACT_NONE)
+        h = ops.mm(noise, tr(W1, Bg, 0, n1), bias=g['fc1.bias'])
+        ops.mm(lab, tr(W1, Bg, n1), out=h, accumulate=True, act=ACT_LRELU)
+        fake = ops.mm(h, tr(g['fc2.weight'], Bg), out=out, bias=g['fc2.bias'], act=ACT_RELU if relu_out else ACT_NONE)
         return fake, h
 
     def generator_bwd(self, dfake, fake, h, g, noise, lab, G, relu_out=True):
@@ -161,18 +184,19 @@ class GanEngine:
         Bg, D = real.shape
         flat, views, scal = zero_grads(Layout.of(d), real.device)
         G = GradDict(views, flat)
-        W1f, w2 = d['fc1.weight'][:, :D], d['fc2.weight'][0]
+        W1, w2 = d['fc1.weight'], d['fc2.weight'][0]
+        W1f, tr = W1[:, :D], _Transposed()
         F = torch.empty((3 * Bg, D), dtype=torch.float32, device=real.device)
         F[:Bg].copy_(real)
         fake = F[Bg:2 * Bg]
-        self.generator_fwd(g, noise, lab, out=fake)
-        lh = self.critic_label_half(d, lab, D)
-        hf = ops.mm(F[:2 * Bg], W1f.t())
+        self.generator_fwd(g, noise, lab, out=fake, tr=tr)
+        lh = ops.mm(lab, tr(W1, Bg, D), bias=d['fc1.bias'])
+        hf = ops.mm(F[:2 * Bg], tr(W1, 2 * Bg, 0, D))
         lst, dhs, sl = ops.gan_critic_head(hf, lh, w2, sim, alpha.reshape(-1), G['fc2.weight'][0], G['fc1.bias'],
                                            scal[0:1])
         gvec = ops.mm(lst[2 * Bg:], W1f, out=F[2 * Bg:])
         ops.gp_rownorm_(gvec, lam, out=scal[1:2])  # gvec <- d gp / d gvec
-        dv = ops.mm(gvec, W1f.t())
+        dv = ops.mm(gvec, tr(W1, Bg, 0, D))
         ops.gp_dw2_(dv, sl, G['fc2.weight'][0])
         ops.mm(lst.t(), F, out=G['fc1.weight'][:, :D])
         ops.mm(dhs.t(), lab, out=G['fc1.weight'][:, D:])
@@ -190,14 +214,15 @@ class GanEngine:
         flat, views, scal = zero_grads(lay, lab.device)
         Gg = GradDict({k[2:]: v for k, v in views.items() if k.startswith('g.')}, flat)
         Gk = GradDict({k[3:]: v for k, v in views.items() if k.startswith('kw.')}, flat) if use_kw else None
+        tr = _Transposed()
         xin = torch.cat([noise, lab], 1)
-        h = ops.mm(xin, g['fc1.weight'].t(), bias=g['fc1.bias'], act=ACT_LRELU)
-        fake = ops.mm(h, g['fc2.weight'].t(), bias=g['fc2.bias'], act=ACT_RELU)
+        h = ops.mm(xin, tr(g['fc1.weight'], Bg), bias=g['fc1.bias'], act=ACT_LRELU)
+        fake = ops.mm(h, tr(g['fc2.weight'], Bg), bias=g['fc2.bias'], act=ACT_RELU)
         D = fake.shape[1]
         dfake = None
         if use_kw:  # decoder_module.py:39-59 with train_gan.py:288-296's row weights
             Wp, We = kw['proj_fc.weight'], kw['word_emb']
-            xk = ops.mm(fake, Wp.t(), bias=kw['proj_fc.bias'])
+            xk = ops.mm(fake, tr(Wp, Bg), bias=kw['proj_fc.bias'])
             logits = ops.mm(xk, We.t())
             ops.keyword_ce_sim_(logits, kw_idx, kw_mask, sim, reg_ratio / Bg, 1.0 / Bg, scal[1:2])  # logits <- d / d logits
             dxk = ops.mm(logits, We)
@@ -205,8 +230,8 @@ class GanEngine:
             ops.colsum(dxk, out=Gk['proj_fc.bias'])
             dfake = ops.mm(dxk, Wp)
         W1f = d['fc1.weight'][:, :D]
-        lh = self.critic_label_half(d, lab, D)
-        hf = ops.mm(fake, W1f.t())
+        lh = ops.mm(lab, tr(d['fc1.weight'], Bg, D), bias=d['fc1.bias'])
+        hf = ops.mm(fake, tr(d['fc1.weight'], Bg, 0, D))
         dh = ops.gan_gen_head(hf, lh, d['fc2.weight'][0], d['fc2.bias'], sim, scal[0:1])
         dfake = ops.mm(dh, W1f, out=dfake, accumulate=dfake is not None)
         ops.act_bwd_(dfake, fake, ACT_RELU)
