@@ -523,6 +523,76 @@ __global__ void logits_bwd_fused_kernel(const float* __restrict__ direct, const 
     }
 }
 
+// The head's backward in one pass over `direct`, one wave per label walking the notes in order (dclf is summed in the
+// same order as dclf_kernel: bit-identical), plus the attention backward's row constant without reading dO or O:
+//   delta[b,l] = sum_f dO[b,l,f] O[b,l,f],  dO = ddirect . Wo,  direct = O . Wo^T + bo
+//              = sum_d ddirect[b,l,d] (direct[b,l,d] - bo[d])
+// (icd_modules.py:142,159: the softmax-backward constant of the pooling that feeds output_proj).  NC = float4 chunks
+// per lane: D <= 256 * NC.
+template <int NC>
+__global__ __launch_bounds__(256) void logits_bwd_delta_kernel(const float* __restrict__ direct,
+                                                               const float* __restrict__ clf,
+                                                               const float* __restrict__ bo,
+                                                               const float* __restrict__ dlogits,
+                                                               float* __restrict__ ddirect, float* __restrict__ dclf,
+                                                               float* __restrict__ delta, int B, int L, int D4) {
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= L) return;
+    float4 c[NC], bb[NC], s[NC];
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const int d4 = lane + 64 * u;
+        const bool ok = d4 < D4;
+        c[u] = ok ? reinterpret_cast<const float4*>(clf)[(long long)l * D4 + d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bb[u] = ok ? reinterpret_cast<const float4*>(bo)[d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // four notes' rows are fetched before the first is consumed (the cross-lane sum at the end of a row would
+    // otherwise keep the next row's loads from issuing)
+    for (int b0 = 0; b0 < B; b0 += 4) {
+        float4 v[4][NC];
+        float g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long row = (long long)min(b0 + q, B - 1) * L + l;
+            g[q] = dlogits[row];
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                const int d4 = min(lane + 64 * u, D4 - 1);
+                v[q][u] = reinterpret_cast<const float4*>(direct)[row * D4 + d4];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (b0 + q >= B) break;
+            const long long row = (long long)(b0 + q) * L + l;
+            float dl = 0.f;
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                const int d4 = lane + 64 * u;
+                if (d4 < D4) {
+                    const float4 x = v[q][u];
+                    float4 o;
+                    o.x = x.x > 0.f ? g[q] * c[u].x : 0.f, o.y = x.y > 0.f ? g[q] * c[u].y : 0.f;
+                    o.z = x.z > 0.f ? g[q] * c[u].z : 0.f, o.w = x.w > 0.f ? g[q] * c[u].w : 0.f;
+                    reinterpret_cast<float4*>(ddirect)[row * D4 + d4] = o;
+                    s[u].x += g[q] * fmaxf(x.x, 0.f), s[u].y += g[q] * fmaxf(x.y, 0.f);
+                    s[u].z += g[q] * fmaxf(x.z, 0.f), s[u].w += g[q] * fmaxf(x.w, 0.f);
+                    dl += o.x * (x.x - bb[u].x) + o.y * (x.y - bb[u].y) + o.z * (x.z - bb[u].z) + o.w * (x.w - bb[u].w);
+                }
+            }
+            dl = wave_sum(dl);
+            if (lane == 0) delta[row] = dl;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+        const int d4 = lane + 64 * u;
+        if (d4 < D4) reinterpret_cast<float4*>(dclf)[(long long)l * D4 + d4] = s[u];
+    }
+}
+
 __global__ void ldam_bce_kernel(const float* __restrict__ logits, const float* __restrict__ y,
                                 const float* __restrict__ margin, float C, float inv_b, float* loss,
                                 float* __restrict__ dlogits, float* __restrict__ probs, int B, int L) {
@@ -883,6 +953,24 @@ extern "C" int gzsl_logits_bwd(const float* direct, const float* clf, const floa
                            B, L, D, accumulate_dclf);
         GZSL_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+extern "C" int gzsl_logits_bwd_delta(const float* direct, const float* clf, const float* bo, const float* dlogits,
+                                     float* ddirect, float* dclf, float* delta, int B, int L, int D, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if ((D & 3) != 0 || D > 1024 ||
+        (((uintptr_t)direct | (uintptr_t)clf | (uintptr_t)bo | (uintptr_t)ddirect | (uintptr_t)dclf) & 15) != 0)
+        return GZSL_EINVAL;
+    const dim3 grid(cdiv(L, 4)), block(256);
+    const int D4 = D / 4;
+#define GZ_LBD(NC) \
+    hipLaunchKernelGGL(logits_bwd_delta_kernel<NC>, grid, block, 0, ST, direct, clf, bo, dlogits, ddirect, dclf, delta, B, L, D4)
+    if (D4 <= 64) GZ_LBD(1);
+    else if (D4 <= 128) GZ_LBD(2);
+    else GZ_LBD(4);
+#undef GZ_LBD
+    GZSL_CHECK_LAUNCH();
     return 0;
 }
 

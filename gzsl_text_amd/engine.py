@@ -190,10 +190,11 @@ class BaseEngine:
         self.ops.attn_fwd(PX, X, Q, l_offset + c0 * L_total, L_total, seed, P_ATTN_DROP if training else 0.0,
                           out=(O[c0:c0 + n], lse[c0:c0 + n]))
 
-    def attn_bwd_block(self, dO, O, lse, PX, X, Q, c0, c1, l_offset, L_total, seed, training, dPX, dX, dQ):
-        """Backward of `attn_fwd_block` for notes [c0, c1): adds into dPX / dX (tensors of THAT block) and dQ."""
+    def attn_bwd_block(self, dO, O, lse, PX, X, Q, c0, c1, l_offset, L_total, seed, training, dPX, dX, dQ, delta=None):
+        """Backward of `attn_fwd_block` for notes [c0, c1): adds into dPX / dX (tensors of THAT block) and dQ.
+        delta [B,L]: rowsum(dO * O) of the whole batch when head_bwd_pre has produced it."""
         self.ops.attn_bwd(dO[c0:c1], O[c0:c1], PX, X, Q, lse[c0:c1], l_offset + c0 * L_total, L_total, seed,
-                          P_ATTN_DROP if training else 0.0, dPX, dX, dQ)
+                          P_ATTN_DROP if training else 0.0, dPX, dX, dQ, delta=None if delta is None else delta[c0:c1])
 
     def head_fwd(self, P, X, PX, Q, clf, l_offset, L_total, seed, training, attn=None):
         """icd_modules.py:137-142,159,177-182 for the label rows [l_offset, l_offset + len(Q)).  attn = (O, lse) when
@@ -209,14 +210,22 @@ class BaseEngine:
         return O, lse, direct, logits
 
     def head_bwd_pre(self, dlogits, O, direct, clf, P):
-        """Classifier + output_proj data gradient: returns (dclf [L,D], dO [B,L,F], pending weight-gradient operands)."""
+        """Classifier + output_proj data gradient: returns (dclf [L,D], dO [B,L,F], pending weight-gradient operands,
+        delta [B,L] = rowsum(dO * O) for the attention backward, or None when it has to be computed from dO and O).
+        delta comes out of the pass over `direct` that produces ddirect: dO = ddirect.Wo and direct = O.Wo^T + bo, so
+        rowsum(dO * O) = rowsum(ddirect * (direct - bo)) -- no separate pass over dO and O (2 x 115 MB at cfg2)."""
         ops = self.ops
         B, L, F_ = O.shape
         D = direct.shape[2]
-        ddirect, dclf = ops.logits_bwd(direct, clf, dlogits, need_ddirect=True)
+        fused = ops.logits_bwd_delta(direct, clf, P['output_proj.bias'], dlogits)
+        if fused is None:
+            ddirect, dclf = ops.logits_bwd(direct, clf, dlogits, need_ddirect=True)
+            delta = None
+        else:
+            ddirect, dclf, delta = fused
         dd2 = ddirect.view(B * L, D)
         dO = ops.mm(dd2, P['output_proj.weight']).view(B, L, F_)
-        return dclf, dO, (dd2, O.view(B * L, F_))
+        return dclf, dO, (dd2, O.view(B * L, F_)), delta
 
     def head_bwd(self, dlogits, O, lse, direct, X, PX, Q, clf, l_offset, L_total, seed, training, P, G,
                  dX, dPX, dQ, need_encoder_grads=True, defer_wgrad=False):
@@ -229,10 +238,11 @@ class BaseEngine:
         if not need_encoder_grads:
             _, dclf = ops.logits_bwd(direct, clf, dlogits, need_ddirect=False)
             return (dclf, None) if defer_wgrad else dclf
-        dclf, dO, pending = self.head_bwd_pre(dlogits, O, direct, clf, P)
+        dclf, dO, pending, delta = self.head_bwd_pre(dlogits, O, direct, clf, P)
         if not defer_wgrad:
             self.head_wgrad(pending, G)
-        ops.attn_bwd(dO, O, PX, X, Q, lse, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0, dPX, dX, dQ)
+        ops.attn_bwd(dO, O, PX, X, Q, lse, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0, dPX, dX, dQ,
+                     delta=delta)
         return (dclf, pending) if defer_wgrad else dclf
 
     def head_wgrad(self, pending, G):

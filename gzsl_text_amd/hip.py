@@ -52,6 +52,7 @@ _PROTOS = {
     'gzsl_gru_seq_step': [c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     'gzsl_logits_fwd': [c_void_p] * 3 + [c_int] * 3 + [c_void_p],
     'gzsl_logits_bwd': [c_void_p] * 5 + [c_int] * 4 + [c_void_p],
+    'gzsl_logits_bwd_delta': [c_void_p] * 7 + [c_int] * 3 + [c_void_p],
     'gzsl_ldam_bce': [c_void_p] * 3 + [c_float, c_float] + [c_void_p] * 3 + [c_int, c_int, c_void_p],
     'gzsl_forward_final': [c_void_p] * 4 + [c_float, c_float] + [c_void_p] * 3 + [c_int, c_int, c_void_p],
     'gzsl_adamw_nobias_step': [c_void_p] * 4 + [c_ll] + [c_float] * 5 + [c_void_p],

@@ -140,12 +140,12 @@ class _BaseModelFn(torch.autograd.Function):
             # other ranks' notes first; the reduce-scatter then starts with a zero own block, and the own block's
             # partial (computed while it is on the wire) is added to the scattered result
             b0, b1 = bs
-            dclf, dO, pending = eng.head_bwd_pre(dlogits, O, direct, clf, P)
+            dclf, dO, pending, delta = eng.head_bwd_pre(dlogits, O, direct, clf, P)
             for c0, c1 in ((0, b0), (b1, X.shape[0])):
                 if c1 > c0:
                     eng.attn_bwd_block(dO, O, lse, PX[c0:c1], X[c0:c1], Q, c0, c1, l0, L, seed, training, dPX[c0:c1],
-                                       dX[c0:c1], davg[l0:l1])
-            own = (dO, torch.zeros_like(dX[b0:b1]), torch.zeros_like(dPX[b0:b1]))
+                                       dX[c0:c1], davg[l0:l1], delta=delta)
+            own = (dO, torch.zeros_like(dX[b0:b1]), torch.zeros_like(dPX[b0:b1]), delta)
         elif bs is not None:
             dclf, pending = eng.head_bwd(dlogits, O, lse, direct, X, PX, Q, clf, l0, L, seed, training, P, G, dX, dPX,
                                          davg[l0:l1], defer_wgrad=True)
@@ -159,9 +159,9 @@ class _BaseModelFn(torch.autograd.Function):
             dXl, hx = sh.reduce_scatter_batch_start(dX)
             dPXl, hp = sh.reduce_scatter_batch_start(dPX)
             if own is not None:
-                dO, dX_own, dPX_own = own
+                dO, dX_own, dPX_own, delta = own
                 eng.attn_bwd_block(dO, O, lse, PX[b0:b1], X[b0:b1], Q, b0, b1, l0, L, seed, training, dPX_own, dX_own,
-                                   davg[l0:l1])
+                                   davg[l0:l1], delta=delta)
             beside = _Beside(dX)
             with beside:  # beside the reduce-scatters and the note encoder's backward (davg is complete by now)
                 eng.label_bwd(davg, dgraph, lcache, P, gb, G)

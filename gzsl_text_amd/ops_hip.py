@@ -289,13 +289,16 @@ class HipOps:
              seed & 0xFFFFFFFF, th, sc)
         return O, lse
 
-    def attn_bwd(self, dO, O, PX, X, Q, lse, l_offset, L_total, seed, p, dPX, dX, dQ, nsplit=None):
-        """Accumulates into dPX [B,Tp,E], dX [B,Tp,F], dQ [L,E]."""
+    def attn_bwd(self, dO, O, PX, X, Q, lse, l_offset, L_total, seed, p, dPX, dX, dQ, nsplit=None, delta=None):
+        """Accumulates into dPX [B,Tp,E], dX [B,Tp,F], dQ [L,E].  delta [B,L] = rowsum(dO * O) when the caller already
+        has it (logits_bwd_delta); computed here from dO and O otherwise."""
         B, Tp, E = PX.shape
         F_ = X.shape[2]
         L = Q.shape[0]
-        delta = torch.empty((B, L), dtype=torch.float32, device=PX.device)
-        call('gzsl_attn_delta', ptr(dO), ptr(O), ptr(delta), B * L, F_)
+        if delta is None:
+            delta = torch.empty((B, L), dtype=torch.float32, device=PX.device)
+            call('gzsl_attn_delta', ptr(dO), ptr(O), ptr(delta), B * L, F_)
+        assert tuple(delta.shape) == (B, L)
         if nsplit is None:
             tok_per_wg = 128 if E <= 100 else 64
             wgs = B * ((Tp + tok_per_wg - 1) // tok_per_wg)
@@ -330,6 +333,19 @@ class HipOps:
         dclf = torch.empty((L, D), dtype=torch.float32, device=direct.device)
         call('gzsl_logits_bwd', ptr(direct), ptr(clf), ptr(dlogits), ptr(ddirect), ptr(dclf), B, L, D, 0)
         return ddirect, dclf
+
+    def logits_bwd_delta(self, direct, clf, bo, dlogits):
+        """(ddirect, dclf, delta): logits_bwd plus the attention backward's row constant delta [B,L] from `direct`
+        and the output_proj bias alone (gzsl_logits_bwd_delta).  None when the shape has no vector path (D % 4)."""
+        B, L, D = direct.shape
+        if D % 4 or D > 1024:
+            return None
+        ddirect = torch.empty_like(direct)
+        dclf = torch.empty((L, D), dtype=torch.float32, device=direct.device)
+        delta = torch.empty((B, L), dtype=torch.float32, device=direct.device)
+        call('gzsl_logits_bwd_delta', ptr(direct), ptr(clf), ptr(bo), ptr(dlogits), ptr(ddirect), ptr(dclf), ptr(delta),
+             B, L, D)
+        return ddirect, dclf, delta
 
     def ldam_bce(self, logits, y, margin, C, inv_b, need_grad=True, need_probs=False):
         B, L = logits.shape

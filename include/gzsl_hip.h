@@ -129,6 +129,12 @@ int gzsl_logits_fwd(const float* direct, const float* clf, float* logits, int B,
 /* ddirect[b,l,d] = dlogits[b,l] * clf[l,d] * (direct > 0);  dclf[l,d] (+)= sum_b dlogits[b,l] * relu(direct[b,l,d]) */
 int gzsl_logits_bwd(const float* direct, const float* clf, const float* dlogits, float* ddirect, float* dclf, int B,
                     int L, int D, int accumulate_dclf, void* stream);
+/* The same two gradients (dclf written, not accumulated) plus delta[b,l] = sum_f dO[b,l,f]*O[b,l,f], the row constant
+ * gzsl_label_attn_bwd needs, obtained WITHOUT dO or O: dO = ddirect.Wo and direct = O.Wo^T + bo (icd_modules.py:159) give
+ * delta = sum_d ddirect[b,l,d]*(direct[b,l,d] - bo[d]); replaces gzsl_attn_delta's pass over 2*B*L*F floats.
+ * D % 4 == 0, D <= 1024, 16-byte aligned buffers (else GZSL_EINVAL: use gzsl_logits_bwd + gzsl_attn_delta). */
+int gzsl_logits_bwd_delta(const float* direct, const float* clf, const float* bo, const float* dlogits, float* ddirect,
+                          float* dclf, float* delta, int B, int L, int D, void* stream);
 /* icd_modules.py:162-172 + BCEWithLogitsLoss(sum) common_module.py:29-30: z = logit - y*margin[l]*C;
  * *loss += sum bce(z,y) * inv_b (atomic; caller zeroes); dlogits = (sigmoid(z) - y) * inv_b.  margin may be NULL. */
 int gzsl_ldam_bce(const float* logits, const float* y, const float* margin, float C, float inv_b, float* loss,

@@ -170,3 +170,41 @@ def run_gan_module_api_check(ops, device):
         close(p.grad, g[f'g0.grad.{k}'], 1e-4, 1e-6, 'generator grad ' + k)
     for k, p in KW.named_parameters():
         close(p.grad, g[f'g0.grad.kw.{k}'], 1e-4, 1e-6, 'keyword head grad ' + k)
+
+
+def run_gan_plain_wgan_check(ops, device):
+    """The branches the goldens do not reach: no sim weights (train_gan.py without --add_zero) and reg_ratio = 0 (no
+    keyword head), one critic + one generator iteration + both Adam steps, against the numpy oracle (oracle/gan.py,
+    itself pinned to the reference by tests/test_oracle_golden.py).  fp32 tolerances as in run_gan_step_check."""
+    from oracle import gan as og
+    s = synth.synth_gan(n_iters=1, **{k: v for k, v in GAN_DIMS['gan_step_tiny'].items() if k != 'n_iters'})
+    d = {k: v.copy() for k, v in s['d'].items()}
+    gen = {k: v.copy() for k, v in s['g'].items()}
+    I, J = s['iters'][0], s['iters'][1]
+    d_cost, gp, gd, fake = og.critic_iteration(d, gen, I['real'], I['lab'], I['noise'], I['alpha'], None)
+    d_after = {k: og.adam_step(d[k], gd[k].reshape(d[k].shape), {}, LR) for k in d}
+    g_cost, kw_loss, gg, kg, gfake = og.generator_iteration(d_after, gen, None, J['lab'], J['noise'], None, None, None, 0.0)
+    g_after = {k: og.adam_step(gen[k], gg[k].reshape(gen[k].shape), {}, LR) for k in gen}
+
+    def dev(x):
+        return {k: torch.from_numpy(v.copy()).to(device) for k, v in x.items()}
+
+    def t(a):
+        return torch.from_numpy(a).to(device)
+
+    step = WganGpStep(ops, dev(s['g']), dev(s['d']), None, lr=LR, critic_iters=1, reg_ratio=0.0)
+    dc, gpv, G, fk = step.critic_step(t(I['real']), t(I['lab']), t(I['noise']), t(I['alpha']), None)
+    close(dc, d_cost, 1e-4, 2e-5, 'd_cost (no sim)')
+    close(gpv, gp, 1e-4, 2e-5, 'gp (no sim)')
+    close(fk, fake, 1e-5, 2e-5, 'fake')
+    for k in G:
+        close(G[k], gd[k].reshape(G[k].shape), 3e-4, 3e-6, f'critic grad {k} (no sim)')
+    gc, kl, Gg, Gk, gfk = step.generator_step(t(J['lab']), t(J['noise']))
+    assert Gk is None and float(kl) == 0.0
+    close(gc, g_cost, 1e-4, 1.5e-4, 'g_cost (no keyword head)')
+    for k in Gg:
+        close(Gg[k], gg[k].reshape(Gg[k].shape), 2e-3, 2e-5, f'generator grad {k} (no keyword head)')
+    for k in step.d:
+        _close_adam(_cut(step.d[k], True), d_after[k], [gd[k].reshape(d[k].shape)], 1, 1e-5, f'critic param {k}')
+    for k in step.g:
+        _close_adam(_cut(step.g[k], True), g_after[k], [gg[k].reshape(gen[k].shape)], 1, 1e-4, f'generator param {k}')

@@ -178,7 +178,7 @@ class CpuOps:
             return out
         return (Pd @ X).contiguous(), lse.contiguous()
 
-    def attn_bwd(self, dO, O, PX, X, Q, lse, l_offset, L_total, seed, p, dPX, dX, dQ, nsplit=None):
+    def attn_bwd(self, dO, O, PX, X, Q, lse, l_offset, L_total, seed, p, dPX, dX, dQ, nsplit=None, delta=None):
         S = torch.einsum('bte,le->blt', PX, Q)
         P = torch.exp(S - lse[:, :, None])
         d = self._attn_drop(PX.shape[0], Q.shape[0], PX.shape[1], l_offset, L_total, seed, p)
@@ -186,7 +186,7 @@ class CpuOps:
         dPd = dO @ X.transpose(1, 2)
         dX += Pd.transpose(1, 2) @ dO
         dP = dPd if d is None else dPd * d
-        delta = (dO * O).sum(2, keepdim=True)
+        delta = (dO * O).sum(2, keepdim=True) if delta is None else delta[:, :, None]
         dS = P * (dP - delta)
         dPX += torch.einsum('blt,le->bte', dS, Q)
         dQ += torch.einsum('blt,bte->le', dS, PX)
@@ -198,6 +198,10 @@ class CpuOps:
         dd = (dlogits[:, :, None] * clf[None] * (direct > 0).float()).contiguous() if need_ddirect else None
         dclf = torch.einsum('bl,bld->ld', dlogits, torch.relu(direct)).contiguous()
         return dd, dclf
+
+    def logits_bwd_delta(self, direct, clf, bo, dlogits):
+        dd, dclf = self.logits_bwd(direct, clf, dlogits)
+        return dd, dclf, (dd * (direct - bo[None, None, :])).sum(2).contiguous()
 
     def ldam_bce(self, logits, y, margin, C, inv_b, need_grad=True, need_probs=False):
         z = logits

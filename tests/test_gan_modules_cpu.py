@@ -34,3 +34,8 @@ def test_label_rnn_mirror_and_cache_match_reference():
         close(forward_enc_hip(enc, ids, m, mode, CpuOps()), g['pool_' + mode], 1e-5, 1e-6, 'packed GRU steps ' + mode)
     cache2 = LabelEncodingCache(enc, ids, m, trunc=20, pool_mode='max', chunk=4, ops=CpuOps())
     close(cache2(sel), g['pool_max'][sel.numpy()], 1e-5, 1e-6, 'cache filled through the step kernels')
+
+
+def test_plain_wgan_step_without_sim_or_keyword_head():
+    from tests.gan_checks import run_gan_plain_wgan_check
+    run_gan_plain_wgan_check(CpuOps(), 'cpu')

@@ -518,6 +518,25 @@ def test_logits_bwd_fused_and_fallback_paths(ops, ref, B, L, D):
     assert none is None and torch.equal(dclf2, dclf)   # same summation order over the notes in both kernels
 
 
+@pytest.mark.parametrize('B,L,D,F', [(3, 37, 24, 40), (16, 300, 200, 200), (2, 70, 400, 200), (5, 9, 1024, 16)])
+def test_logits_bwd_with_attention_delta(ops, ref, B, L, D, F):
+    """gzsl_logits_bwd_delta: ddirect / dclf as gzsl_logits_bwd, and delta = rowsum(dO * O) obtained from `direct` and the
+    output_proj bias alone, against the definition (dO = ddirect @ Wo, then gzsl_attn_delta's sum)."""
+    rs = np.random.RandomState(B * 1000 + L + D)
+    O, Wo, bo = rnd(rs, B, L, F), rnd(rs, D, F, scale=0.2), rnd(rs, D)
+    clf, dlogits = rnd(rs, L, D), rnd(rs, B, L)
+    direct = O @ Wo.t() + bo
+    dd_r, dclf_r = ref.logits_bwd(direct, clf, dlogits)
+    delta_r = ((dd_r.double() @ Wo.double()) * O.double()).sum(2).float()
+    dd, dclf, delta = ops.logits_bwd_delta(g(direct), g(clf), g(bo), g(dlogits))
+    close(dd, dd_r, 1e-6, 1e-7, 'ddirect')
+    close(dclf, dclf_r, 1e-5, 2e-6 * np.sqrt(B), 'dclf')
+    # fp32: direct - bo recovers O.Wo^T up to one rounding of |direct| per term
+    close(delta, delta_r, 1e-4, 3e-6 * np.sqrt(D) * float(direct.abs().max() * dd_r.abs().max()), 'delta')
+    dd2, dclf2 = ops.logits_bwd(g(direct), g(clf), g(dlogits))
+    assert torch.equal(dd2, dd) and torch.equal(dclf2, dclf)  # same arithmetic, same summation order over notes
+
+
 def test_ldam_bce_many_blocks(ops, ref):
     rs = np.random.RandomState(12)
     B, L = 16, 9000

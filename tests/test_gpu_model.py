@@ -132,6 +132,13 @@ def test_deterministic_mode_is_bit_reproducible(name):
         Beside.serial = False
 
 
+def test_gan_plain_wgan_step_on_hip():
+    """No sim weights, no keyword head: the branches of the whole-iteration engine the goldens do not reach."""
+    from gzsl_text_amd.ops_hip import HipOps
+    from tests.gan_checks import run_gan_plain_wgan_check
+    run_gan_plain_wgan_check(HipOps(), 'cuda')
+
+
 def test_gan_step_replayed_as_hip_graph_matches_eager():
     """The whole WGAN-GP step (critic iterations + generator iteration + Adam) records into one HIP graph: nothing in
     the C ABI allocates or synchronises.  One eager step plus three replays must land on the parameters four eager steps reach."""

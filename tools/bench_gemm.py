@@ -34,10 +34,11 @@ def timeit(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--E', type=int, default=100, help='E = H; D = 2E (200: the width the reference drivers build)')
     args = ap.parse_args()
     dev = 'cuda'
     ops = HipOps()
-    B, T, E, F, k, L, N, H, D = 16, 2500, 100, 200, 10, 9000, 12000, 100, 200
+    B, T, E, F, k, L, N, H, D = 16, 2500, args.E, 200, 10, 9000, 12000, args.E, 2 * args.E
     Tp = T - k + 1
     g = torch.Generator(device=dev).manual_seed(0)
 
@@ -73,6 +74,15 @@ def main():
     add('gru fwd       12000x300x100  KC/KC', 2.0 * N * 3 * H * H, lambda: ops.linear(hN, Wih))
     add('gru dgrad     12000x100x300  KC/RC', 2.0 * N * 3 * H * H, lambda: ops.mm(dg, Wih))
     add('gru wgrad     300x100x12000  RC/RC', 2.0 * N * 3 * H * H, lambda: ops.mm(dg.t(), hN))
+    if os.environ.get('GZ_RC_B') == '1':  # forward products with the weight stored [K,N] (B contiguous along its rows)
+        Wpt, Wot, Wiht = Wp.t().contiguous(), Wo.t().contiguous(), Wih.t().contiguous()
+        A = rnd(M1, E * k)
+        Wck, Wckt = Wc.view(F, E * k), Wc.view(F, E * k).t().contiguous()
+        add('plain 39856x200x1000  KC/KC', 2.0 * M1 * F * E * k, lambda: ops.mm(A, Wck.t(), bias=bc, act=ACT_RELU))
+        add('plain 39856x200x1000  KC/RC', 2.0 * M1 * F * E * k, lambda: ops.mm(A, Wckt, bias=bc, act=ACT_RELU))
+        add('proj+tanh  KC/RC', 2.0 * M1 * E * F, lambda: ops.mm(X.view(M1, F), Wpt, bias=bp, act=ACT_TANH))
+        add('outproj fwd KC/RC', 2.0 * B * L * F * D, lambda: ops.mm(O, Wot, bias=bo, act=ACT_RELU))
+        add('gru fwd KC/RC', 2.0 * N * 3 * H * H, lambda: ops.mm(hN, Wiht))
     if os.environ.get('GZ_TORCH_MM') == '1':  # what the vendor library (rocBLAS / hipBLASLt through torch.mm) does on the same shapes
         add('torch.mm outproj fwd  144000x200x200', 2.0 * B * L * F * D, lambda: torch.mm(O, Wo.t()))
         add('torch.mm outproj dgrad', 2.0 * B * L * F * D, lambda: torch.mm(dDir, Wo))
