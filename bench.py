@@ -128,6 +128,7 @@ def hbm_bytes(d, B, nnz):
         'gru_gate_bwd': 2 * 15 * N * H * 4,                                # + dhn in, dgi, dgh, dh out
         'logits_fwd': B * L * D * 4 + L * D * 4 + B * L * 4,
         'logits_bwd': 2 * B * L * D * 4 + 2 * L * D * 4 + B * L * 4,
+        'logits_bwd_delta': 2 * B * L * D * 4 + 2 * L * D * 4 + 2 * B * L * 4 + D * 4,  # + delta out (replaces attn_delta)
         'attn_delta': 2 * B * L * F * 4 + B * L * 4,
         'ldam_bce': 3 * B * L * 4 + L * 4,
     }
@@ -136,7 +137,7 @@ def hbm_bytes(d, B, nnz):
 def hbm_pass(model, step, timer_ops, d, B, steps=5):
     """Short pass after the timed region: event-time every HBM-bound kernel of the step and report achieved GB/s."""
     names = ['emb_gather', 'emb_scatter_add_', 'label_avg', 'label_avg_bwd_', 'spmm', 'gru_gate_fwd', 'gru_gate_bwd',
-             'logits_fwd', 'logits_bwd', 'ldam_bce']
+             'logits_fwd', 'logits_bwd', 'logits_bwd_delta', 'ldam_bce']
     ops = timer_ops
     t = KernelTimer(ops, names)
     # attn_delta is launched inside HipOps.attn_bwd: time it through the C-ABI call table
