@@ -113,22 +113,58 @@ __global__ void weighted_sum_kernel(const float* __restrict__ x, const float* __
     if ((threadIdx.x & 63) == 0) atomicAdd(out, part * scale);
 }
 
-__global__ void rowdot_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w,
-                                  const float* __restrict__ act, float* __restrict__ da, float* dw, float* db, int Bg,
-                                  int H, int rows_per_block, int lrelu_in) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = min(Bg, r0 + rows_per_block);
-    if (col < H) {
-        const float wj = w[col];
-        float acc = 0.f;
-        for (int r = r0; r < r1; ++r) {
-            float a = act[(long long)r * H + col];
+// Column-owner layout of the head kernels below: a lane owns V adjacent columns and walks the rows of its row block
+// (interleaved over the block's waves); dw stays in registers until one atomic per column and row block.
+template <int V>
+__global__ __launch_bounds__(1024) void rowdot_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                          const float* __restrict__ act, float* __restrict__ da, float* dw,
+                                                          float* db, int Bg, int H, int rb, int lrelu_in) {
+    __shared__ float red[16][64 * V];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * V;
+    const bool live = col < H;
+    const int r0 = blockIdx.y * rb, r1 = min(Bg, r0 + rb);
+    float wj[V], acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) wj[i] = live ? w[col + i] : 0.f, acc[i] = 0.f;
+    if (live) {
+        for (int r = r0 + wv; r < r1; r += nw) {
             const float d = dout[r];
-            acc += d * ((lrelu_in && a <= 0.f) ? 0.2f * a : a);
-            if (da) da[(long long)r * H + col] = d * wj * (a > 0.f ? 1.f : 0.2f);
+            const long long o = (long long)r * H + col;
+            float a[V], g[V];
+            if (V == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(act + o);
+#pragma unroll
+                for (int i = 0; i < V; ++i) a[i] = t[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) a[i] = act[o + i];
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                acc[i] += d * ((lrelu_in && a[i] <= 0.f) ? 0.2f * a[i] : a[i]);
+                g[i] = d * wj[i] * (a[i] > 0.f ? 1.f : 0.2f);
+            }
+            if (da) {
+                if (V == 4) *reinterpret_cast<f32x4*>(da + o) = f32x4{g[0], g[1 % V], g[2 % V], g[3 % V]};
+                else
+#pragma unroll
+                    for (int i = 0; i < V; ++i) da[o + i] = g[i];
+            }
         }
-        if (dw) atomicAdd(dw + col, acc);
+    }
+    if (dw) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) red[wv][lane * V + i] = acc[i];
+        __syncthreads();
+        if (wv == 0 && live) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float t = 0.f;
+                for (int u = 0; u < nw; ++u) t += red[u][lane * V + i];
+                atomicAdd(dw + col + i, t);
+            }
+        }
     }
     if (db && blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
@@ -582,9 +618,11 @@ extern "C" int gzsl_weighted_sum(const float* x, const float* w, float scale, fl
 extern "C" int gzsl_rowdot_bwd(const float* dout, const float* w, const float* act, float* da, float* dw, float* db,
                                int Bg, int H, int lrelu_in, void* stream) {
     if (Bg <= 0) return 0;
-    const int rpb = 64;
-    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(cdiv(H, 256), cdiv(Bg, rpb)), dim3(256), 0, ST, dout, w, act, da, dw, db,
-                       Bg, H, rpb, lrelu_in);
+    const bool v4 = (H & 3) == 0 && al16(act) && (!da || al16(da));
+    const int rb = head_rb(Bg);
+    const dim3 grid(cdiv(v4 ? H / 4 : H, 64), cdiv(Bg, rb)), block(head_threads(Bg));
+    if (v4) hipLaunchKernelGGL(rowdot_bwd_kernel<4>, grid, block, 0, ST, dout, w, act, da, dw, db, Bg, H, rb, lrelu_in);
+    else hipLaunchKernelGGL(rowdot_bwd_kernel<1>, grid, block, 0, ST, dout, w, act, da, dw, db, Bg, H, rb, lrelu_in);
     GZSL_CHECK_LAUNCH();
     return 0;
 }

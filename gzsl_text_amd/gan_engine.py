@@ -118,13 +118,14 @@ class GanEngine:
         """lab @ W1[:, D:]^T + b1, shared by every critic evaluation on the same labels."""
         return self.ops.mm(lab, d['fc1.weight'][:, D:].t(), bias=d['fc1.bias'])
 
-    def critic_fwd(self, d, feat, lab_half):
-        """Returns (logits [Bg], fc1 pre-activations [Bg, ndh])."""
+    def critic_fwd(self, d, feat, lab_half, consume=False, need_logits=True):
+        """Returns (logits [Bg] or None, fc1 pre-activations [Bg, ndh]).  consume=True: `lab_half` is not needed again and
+        becomes the pre-activation buffer (no copy)."""
         ops = self.ops
         D = feat.shape[1]
-        h = lab_half.clone()
+        h = lab_half if consume else lab_half.clone()
         ops.mm(feat, d['fc1.weight'][:, :D].t(), out=h, accumulate=True)
-        logits = ops.rowdot(h, d['fc2.weight'][0], d['fc2.bias'], lrelu_in=True)
+        logits = ops.rowdot(h, d['fc2.weight'][0], d['fc2.bias'], lrelu_in=True) if need_logits else None
         return logits, h
 
     def critic_bwd(self, dout, h, d, G=None, need_dh=True):

@@ -12,7 +12,7 @@ in `Variable(...)`); the critic's `feat` input does receive a gradient (generato
 import torch
 import torch.nn as nn
 
-from ..gan_engine import GanEngine
+from ..gan_engine import GanEngine, Layout, zero_grads
 
 
 def _ops_of(module):
@@ -26,6 +26,13 @@ def _ops_of(module):
 
 def _pd(module):
     return {k: v.detach() for k, v in module.named_parameters()}
+
+
+def _zero_like_params(params, keys=None):
+    """Zeroed gradient tensors for `params` carved out of one buffer (one fill launch, 256-byte aligned tensors)."""
+    keys = list(params) if keys is None else keys
+    ref = params[keys[0]]
+    return zero_grads(Layout([(k, params[k].shape) for k in keys]), ref.device)[1]
 
 
 class _GeneratorFn(torch.autograd.Function):
@@ -42,7 +49,7 @@ class _GeneratorFn(torch.autograd.Function):
     def backward(ctx, dout):
         g, noise, label, h = ctx.state
         eng = GanEngine(_ops_of(ctx.mod))
-        G = {k: torch.zeros_like(v) for k, v in g.items()}
+        G = _zero_like_params(g)
         eng.generator_bwd(dout.contiguous().clone(), None, h, g, noise, label, G, relu_out=False)
         return (None, None, None) + tuple(G[k] for k in ctx.mod._names)
 
@@ -72,7 +79,7 @@ class _CriticFn(torch.autograd.Function):
         d = dict(zip(mod._names, [p.detach() for p in params]))
         f, label = feat.detach().contiguous(), label.detach().contiguous()
         lab_half = eng.critic_label_half(d, label, f.shape[1])
-        logits, h = eng.critic_fwd(d, f, lab_half)
+        logits, h = eng.critic_fwd(d, f, lab_half, consume=True)
         ctx.mod, ctx.state = mod, (d, f, label, h)
         ctx.need_feat = feat.requires_grad
         ctx.need_params = any(p.requires_grad for p in params)
@@ -82,7 +89,7 @@ class _CriticFn(torch.autograd.Function):
     def backward(ctx, dout):
         d, f, label, h = ctx.state
         eng = GanEngine(_ops_of(ctx.mod))
-        G = {k: torch.zeros_like(v) for k, v in d.items()} if ctx.need_params else None
+        G = _zero_like_params(d) if ctx.need_params else None
         dh = eng.critic_bwd(dout.contiguous(), h, d, G)
         if G is not None:
             eng.critic_fc1_grads(dh, f, label, G)
@@ -118,9 +125,11 @@ class _GradPenaltyFn(torch.autograd.Function):
         real, fake, labels = real.detach().contiguous(), fake.detach().contiguous(), labels.detach().contiguous()
         D = real.shape[1]
         lab_half = eng.critic_label_half(d, labels, D)
-        _, h_real = eng.critic_fwd(d, real, lab_half)
-        _, h_fake = eng.critic_fwd(d, fake, lab_half)
-        G = {k: torch.zeros_like(v) for k, v in d.items()}
+        _, h_real = eng.critic_fwd(d, real, lab_half, need_logits=False)
+        _, h_fake = eng.critic_fwd(d, fake, lab_half, consume=True, need_logits=False)
+        # the penalty depends on the parameters only through fc1.weight[:, :D] and fc2.weight (the slope mask is
+        # piecewise constant): the two biases get no gradient (autograd leaves exact zeros there; None adds nothing)
+        G = _zero_like_params(d, ('fc1.weight', 'fc2.weight'))
         gp = eng.gradient_penalty(d, h_real, h_fake, alpha, D, G, lam)
         ctx.mod, ctx.G = mod, G
         return gp
@@ -128,14 +137,20 @@ class _GradPenaltyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dgp):
         G = ctx.G
-        return (None,) * 6 + tuple(G[k] * dgp for k in ctx.mod._names)
+        return (None,) * 6 + tuple((G[k] * dgp if k in G else None) for k in ctx.mod._names)
 
 
 def calc_gradient_penalty(discriminator, real_feats, fake_feats, labels, lambda1=10.):
     """generative_module.py:22-38.  alpha is drawn exactly as the reference draws it (torch.rand(b, 1) on the host,
     then moved to the device), so the same torch seed gives the same interpolation points."""
     b = real_feats.size(0)
-    alpha = torch.rand(b, 1).to(real_feats.device)
+    alpha = torch.rand(b, 1)  # the reference's draw: host generator, [b, 1]
+    if real_feats.is_cuda:
+        # a pageable H2D copy waits for everything queued on the stream (0.8 ms per critic iteration at batch 8, five
+        # times per step): stage through pinned memory and let the copy queue behind the kernels instead
+        alpha = alpha.pin_memory().to(real_feats.device, non_blocking=True)
+    else:
+        alpha = alpha.to(real_feats.device)
     d = dict(discriminator.named_parameters())
     return _GradPenaltyFn.apply(discriminator, real_feats, fake_feats, labels, alpha, float(lambda1),
                                 *[d[k] for k in discriminator._names])
