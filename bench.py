@@ -16,8 +16,9 @@ loss.mean().backward(), Adam(lr 1e-3, wd 1e-5).step().  Inputs are resident in H
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      dominant kernel (label_attn_bwd), timed with events on the launch stream INSIDE the timed region;
                 .also: forward attention, whole step, at N=1 the same numbers at E=H=200 (`real_e200`, separate short
-                pass) and achieved GB/s of every HBM-bound kernel of the step (`hbm`, separate short pass; algorithmic
-                bytes as SURVEY.md 8d / DESIGN.md 4 state them, peak 8 TB/s)
+                pass), achieved GB/s of every HBM-bound kernel of the step (`hbm`, separate short pass; algorithmic
+                bytes as SURVEY.md 8d / DESIGN.md 4 state them, peak 8 TB/s) and forward-only eval scoring of the
+                same batch (`eval_forward`)
   cpu_baseline  (N=1) the numpy oracle timed on the host cores on a bounded sample of the same workload
   comm          (N>1) per collective: ms per step the launching stream sat blocked on it (exposed communication) and
                 bytes per call; plus ms/step of a short pass with the own-notes-first ordering switched the other way.
@@ -216,6 +217,27 @@ def attention_lines(timer, d, B, L_local):
     bwd_ms, fwd_ms = timer.mean_ms('attn_bwd_main'), timer.mean_ms('attn_fwd')
     fl = algorithmic_flops(d, B, L_local)
     return bwd_ms, fwd_ms, fl
+
+
+def eval_forward_pass(model, x, y, mask, d, steps=10):
+    """Forward-only scoring of the same batch (train_base.py:118-140's loop body; BASELINE configs[4] "full-label eval
+    scoring" on one GPU): eval mode, no dropout, torch.no_grad()."""
+    model.eval()
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                model(x, y, mask)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model(x, y, mask)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+    finally:
+        model.train()
+    fwd = step_flops(d, d['B']) / 3.0
+    return {'config': f'eval mode, no_grad, same batch; {steps} passes', 'ms_per_batch': dt * 1e3, 'notes_per_s': d['B'] / dt,
+            'frac_of_fp32_matrix_peak': fwd / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
 
 def real_e200_pass(args, dev, steps=5):
@@ -428,6 +450,7 @@ def main():
     if world == 1 and not args.no_extras:
         try:
             out['roofline']['also']['hbm'] = hbm_pass(model, step, ops, d, B)
+            out['roofline']['also']['eval_forward'] = eval_forward_pass(model, x, y, mask, d)
             if args.config == 'cfg2' and args.E == 100:
                 del model, opt
                 torch.cuda.empty_cache()
