@@ -278,23 +278,33 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
     int ki0 = kbeg - kb0 * k_inner;
     typename Mover<BM, BM, A_RC, VEC>::Tile ga;
     typename Mover<BN, BNP, B_RC, VEC>::Tile gb;
-    // tiles [0, nfull) take the fast path (see Mover::load_fast); the K tail, windowed operands (conv data gradient) and
-    // k-batched operands (conv weight gradient) take the masked one
-    const bool fast = VEC && k_inner >= g.K && g.a_span == 0x7FFFFFFFu && g.a_shift == 0;
-    const int nfull = fast ? (kend - kbeg) / BK : 0;
+    // A k-tile takes the fast path (see Mover::load_fast) when it lies wholly inside K and inside ONE k batch, and the
+    // workgroup's rows need no window test: either the operand has no window, or (conv data gradient) all BM rows are
+    // real rows of one note whose windows lie inside the note for every k -- 36 of a note's 39 row tiles; the tiles at the
+    // note boundaries, the K tail and k-tiles that straddle two k batches (conv weight gradient: 1 in 155) are masked.
+    bool rows_fast = VEC && g.a_span == 0x7FFFFFFFu && g.a_shift == 0;
+    if (VEC && !rows_fast && g.a_sm >= 0 && g.a_sk >= 0) {
+        const int mlast = m0 + BM - 1;
+        if (mlast < g.M && m0 / g.a_mb == mlast / g.a_mb) {
+            const long long lo = (long long)(m0 % g.a_mb) * g.a_sm + g.a_shift;
+            const long long hi = (long long)(mlast % g.a_mb) * g.a_sm + g.a_shift +
+                                 (long long)(min(g.K, k_inner) - 1) * g.a_sk + (A_RC ? 0 : 3);
+            rows_fast = lo >= 0 && hi < (long long)g.a_span;
+        }
+    }
     bool in_regs_fast = false;  // which path fetched the tile now in registers
     auto fetch = [&](int t) {   // tile t -> registers (t >= ntile: masked to zeros, addresses clamped: harmless)
+        const bool tf = rows_fast && k_next + BK <= kend && ki0 + BK <= k_inner;
         if (!(GZ_GEMM_ABL & 1)) {
-            if (t < nfull) {
-                const long long k0 = kbeg + (long long)t * BK;
-                ma.load_fast(oa.p + k0 * oa.sk, ga);
-                mb.load_fast(ob.p + k0 * ob.sk, gb);
+            if (tf) {
+                ma.load_fast(oa.p + (long long)kb0 * oa.kbs + (long long)ki0 * oa.sk, ga);
+                mb.load_fast(ob.p + (long long)kb0 * ob.kbs + (long long)ki0 * ob.sk, gb);
             } else {
                 ma.load(oa, k_next, kb0, ki0, kend, k_inner, ga);
                 mb.load(ob, k_next, kb0, ki0, kend, k_inner, gb);
             }
         }
-        in_regs_fast = t < nfull;
+        in_regs_fast = tf;
         k_next += BK;
         ki0 += BK;
         if (ki0 >= k_inner) {
