@@ -14,6 +14,7 @@ Extra, not in the reference:
   * `set_dropout_seed(seed)`: base seed of the counter RNG that replaces torch's dropout stream; the seed of a
     forward is base + number of training forwards so far (all ranks must use the same base).
 """
+import math
 import os
 from collections import OrderedDict
 
@@ -130,10 +131,13 @@ class _BaseModelFn(torch.autograd.Function):
         L = mod.eval_code_size
         G = FlatGrads(P, names)
         dlogits = dlogits * dloss  # upstream scalar (train_base.py:112 backpropagates loss.mean(): 1.0)
-        dX = torch.zeros_like(X)
-        dPX = torch.zeros_like(PX)
-        davg = torch.zeros(avg_shape, dtype=torch.float32, device=X.device)
-        dgraph = torch.zeros(graph_shape, dtype=torch.float32, device=X.device)
+        # the four accumulation targets of the backward, carved from ONE zero-filled buffer (one fill launch; 256-byte
+        # aligned pieces): the kernels below add into them with atomics / accumulate epilogues
+        shapes = (tuple(X.shape), tuple(PX.shape), tuple(avg_shape), tuple(graph_shape))
+        sizes = [-(-math.prod(sh_) // 64) * 64 for sh_ in shapes]
+        zbuf = torch.zeros(sum(sizes), dtype=torch.float32, device=X.device)
+        dX, dPX, davg, dgraph = (zbuf[o:o + math.prod(sh_)].view(sh_)
+                                 for o, sh_ in zip((0, sizes[0], sizes[0] + sizes[1], sum(sizes[:3])), shapes))
         pending = None
         own = None
         if bs is not None and sh.own_first and sh.world > 1:
