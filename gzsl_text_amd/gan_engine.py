@@ -178,9 +178,10 @@ class GanEngine:
     #   lst = [dh_real; dh_fake; v]             [3Bg, ndh]   d fc1.weight[:, :D] = lst^T @ F  (K = 3Bg, no accumulation)
     # and run everything between those GEMMs in one kernel (gzsl_gan_critic_head / gzsl_gan_gen_head).  Every gradient
     # tensor is written by exactly one GEMM / column sum, or accumulated by kernels ordered on the stream.
-    def critic_iteration(self, d, g, real, lab, noise, alpha, sim=None, lam=10.0):
+    def critic_iteration(self, d, g, real, lab, noise, alpha, sim=None, lam=10.0, fake=None):
         """train_gan.py:228-259 up to optimizer_d.step().  Returns (d_cost, gp, grads for d, fake); the grads dict
-        carries `.flat`, the buffer its tensors are views of (laid out as Layout.of(d))."""
+        carries `.flat`, the buffer its tensors are views of (laid out as Layout.of(d)).  fake: relu(G(noise, lab)) when
+        the caller has it already (WganGpStep.full_step runs the generator once for all critic iterations)."""
         ops = self.ops
         Bg, D = real.shape
         flat, views, scal = zero_grads(Layout.of(d), real.device)
@@ -189,8 +190,12 @@ class GanEngine:
         W1f, tr = W1[:, :D], _Transposed()
         F = torch.empty((3 * Bg, D), dtype=torch.float32, device=real.device)
         F[:Bg].copy_(real)
-        fake = F[Bg:2 * Bg]
-        self.generator_fwd(g, noise, lab, out=fake, tr=tr)
+        if fake is None:
+            fake = F[Bg:2 * Bg]
+            self.generator_fwd(g, noise, lab, out=fake, tr=tr)
+        else:
+            F[Bg:2 * Bg].copy_(fake)
+            fake = F[Bg:2 * Bg]
         lh = ops.mm(lab, tr(W1, Bg, D), bias=d['fc1.bias'])
         hf = ops.mm(F[:2 * Bg], tr(W1, 2 * Bg, 0, D))
         lst, dhs, sl = ops.gan_critic_head(hf, lh, w2, sim, alpha.reshape(-1), G['fc2.weight'][0], G['fc1.bias'],
@@ -302,6 +307,31 @@ class WganGpStep:
         d_cost, gp, G, fake = self.eng.critic_iteration(self.d, self.g, real, lab, noise, alpha, sim, self.lam)
         self._adam('d', self._pd, G.flat)
         return d_cost, gp, G, fake
+
+    def full_step(self, critic_batches, gen_batch):
+        """One WGAN-GP step with all of its batches in hand: critic_batches = list of (real, lab, noise, alpha, sim),
+        gen_batch = (lab, noise, sim, kw_idx, kw_mask).  The generator does not change while the critic trains
+        (train_gan.py:225-259 only steps optimizer_d), so its forward for ALL critic iterations is one stacked pass
+        (three GEMMs over critic_iters * Bg rows instead of 3 * critic_iters over Bg rows).  Same results as
+        critic_step x n + generator_step.  Returns (list of (d_cost, gp), (g_cost, kw_loss))."""
+        Bg = critic_batches[0][0].shape[0]
+        # stacking pays where a Bg-row product leaves the GPU underfilled but is past the skinny kernel's 32 rows
+        # (measured: Bg=4096 3.47 -> 3.35 ms; Bg=8 would trade five 5-us skinny products for a 25-us tiled one)
+        stack = self.STACK_MIN_ROWS <= Bg < self.STACK_MAX_ROWS
+        if stack:
+            noise_all = torch.cat([b[2] for b in critic_batches], 0)
+            lab_all = torch.cat([b[1] for b in critic_batches], 0)
+            fake_all, _ = self.eng.generator_fwd(self.g, noise_all, lab_all)
+        costs = []
+        for i, (real, lab, noise, alpha, sim) in enumerate(critic_batches):
+            d_cost, gp, G, _ = self.eng.critic_iteration(self.d, self.g, real, lab, noise, alpha, sim, self.lam,
+                                                         fake=fake_all[i * Bg:(i + 1) * Bg] if stack else None)
+            self._adam('d', self._pd, G.flat)
+            costs.append((d_cost, gp))
+        g_cost, kw_loss = self.generator_step(*gen_batch)[:2]
+        return costs, (g_cost, kw_loss)
+
+    STACK_MIN_ROWS, STACK_MAX_ROWS = 64, 8192
 
     def generator_step(self, lab, noise, sim=None, kw_idx=None, kw_mask=None):
         g_cost, kw_loss, Gg, Gk, fake = self.eng.generator_iteration(self.d, self.g, self.kw, lab, noise, sim, kw_idx,

@@ -208,3 +208,43 @@ def run_gan_plain_wgan_check(ops, device):
         _close_adam(_cut(step.d[k], True), d_after[k], [gd[k].reshape(d[k].shape)], 1, 1e-5, f'critic param {k}')
     for k in step.g:
         _close_adam(_cut(step.g[k], True), g_after[k], [gg[k].reshape(gen[k].shape)], 1, 1e-4, f'generator param {k}')
+
+
+def run_gan_full_step_check(ops, device):
+    """WganGpStep.full_step (generator forward of all critic iterations in one stacked pass) lands on the parameters of
+    critic_step x n + generator_step: same arithmetic per row, so fp32-tight."""
+    name = 'gan_step_tiny'
+    kwargs = dict(GAN_DIMS[name])
+    n_iters = kwargs.pop('n_iters')
+    s = synth.synth_gan(n_iters=n_iters, **kwargs)
+
+    def dev(x):
+        return {k: torch.from_numpy(v.copy()).to(device) for k, v in x.items()}
+
+    def t(a):
+        return torch.from_numpy(a).to(device)
+
+    its = [{k: t(v) for k, v in I.items()} for I in s['iters']]
+    kw_idx, kw_mask = t(s['kw_idx']), t(s['kw_mask'])
+    a = WganGpStep(ops, dev(s['g']), dev(s['d']), dev(s['kw']), lr=LR, critic_iters=n_iters, reg_ratio=0.01)
+    b = WganGpStep(ops, dev(s['g']), dev(s['d']), dev(s['kw']), lr=LR, critic_iters=n_iters, reg_ratio=0.01)
+    b.STACK_MIN_ROWS = 1  # the tiny case has 6 rows: force the stacked generator pass
+    want = []
+    for i in range(n_iters):
+        I = its[i]
+        want.append(a.critic_step(I['real'], I['lab'], I['noise'], I['alpha'], I['sim'])[:2])
+    I = its[n_iters]
+    g_want = a.generator_step(I['lab'], I['noise'], I['sim'], kw_idx, kw_mask)[:2]
+    costs, g_got = b.full_step([(I['real'], I['lab'], I['noise'], I['alpha'], I['sim']) for I in its[:n_iters]],
+                               (I['lab'], I['noise'], I['sim'], kw_idx, kw_mask))
+    for (dc, gp), (dc2, gp2) in zip(want, costs):
+        close(dc2, _cut(dc, True), 1e-5, 1e-6, 'd_cost')
+        close(gp2, _cut(gp, True), 1e-5, 1e-6, 'gp')
+    close(g_got[0], _cut(g_want[0], True), 1e-5, 1e-6, 'g_cost')
+    close(g_got[1], _cut(g_want[1], True), 1e-5, 1e-6, 'kw_loss')
+    for k in a.d:
+        close(b.d[k], _cut(a.d[k], True), 1e-6, 2.02 * LR * n_iters, 'critic parameters ' + k)
+        assert float((b.d[k] - a.d[k]).abs().mean()) < 1e-6, k
+    for k in a.g:
+        close(b.g[k], _cut(a.g[k], True), 1e-6, 2.02 * LR, 'generator parameters ' + k)
+        assert float((b.g[k] - a.g[k]).abs().mean()) < 1e-6, k

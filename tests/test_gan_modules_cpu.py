@@ -39,3 +39,8 @@ def test_label_rnn_mirror_and_cache_match_reference():
 def test_plain_wgan_step_without_sim_or_keyword_head():
     from tests.gan_checks import run_gan_plain_wgan_check
     run_gan_plain_wgan_check(CpuOps(), 'cpu')
+
+
+def test_full_step_matches_per_iteration_steps():
+    from tests.gan_checks import run_gan_full_step_check
+    run_gan_full_step_check(CpuOps(), 'cpu')

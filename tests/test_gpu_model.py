@@ -139,6 +139,12 @@ def test_gan_plain_wgan_step_on_hip():
     run_gan_plain_wgan_check(HipOps(), 'cuda')
 
 
+def test_gan_full_step_matches_per_iteration_steps_on_hip():
+    from gzsl_text_amd.ops_hip import HipOps
+    from tests.gan_checks import run_gan_full_step_check
+    run_gan_full_step_check(HipOps(), 'cuda')
+
+
 def test_gan_step_replayed_as_hip_graph_matches_eager():
     """The whole WGAN-GP step (critic iterations + generator iteration + Adam) records into one HIP graph: nothing in
     the C ABI allocates or synchronises.  One eager step plus three replays must land on the parameters four eager steps reach."""

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reg-ratio', type=float, default=0.1)
+    ap.add_argument('--per-iteration', action='store_true', help='critic_step x 5 + generator_step instead of full_step')
     ap.add_argument('--graph', action='store_true', help='replay the step as one HIP graph (small batches are launch-bound)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
@@ -40,11 +41,15 @@ def main():
     kw_idx, kw_mask = torch.from_numpy(case['kw_idx']).to(dev), torch.from_numpy(case['kw_mask']).to(dev)
 
     def one():
-        for i in range(5):
-            it = its[i]
-            step.critic_step(it['real'], it['lab'], it['noise'], it['alpha'], it['sim'])
+        if args.per_iteration:
+            for i in range(5):
+                it = its[i]
+                step.critic_step(it['real'], it['lab'], it['noise'], it['alpha'], it['sim'])
+            it = its[5]
+            return step.generator_step(it['lab'], it['noise'], it['sim'], kw_idx, kw_mask)[0]
+        cb = [(it['real'], it['lab'], it['noise'], it['alpha'], it['sim']) for it in its[:5]]
         it = its[5]
-        return step.generator_step(it['lab'], it['noise'], it['sim'], kw_idx, kw_mask)[0]
+        return step.full_step(cb, (it['lab'], it['noise'], it['sim'], kw_idx, kw_mask))[1][0]
 
     if args.graph:
         one = graphed_step(one)
