@@ -36,6 +36,7 @@ class HipOps:
     def __init__(self, deterministic=None):
         import os
         self.deterministic = (os.environ.get('GZSL_DETERMINISTIC') == '1') if deterministic is None else bool(deterministic)
+        self.attn_bf16x6 = os.environ.get('GZSL_ATTN_BF16X6') == '1'  # experimental forward attention, off by default
         if self.deterministic:
             from .streams import Beside
             Beside.serial = True
@@ -285,6 +286,13 @@ class HipOps:
             O, lse = out
             assert tuple(O.shape) == (B, L, F_) and tuple(lse.shape) == (B, L)
         th, sc = drop_params(p)
+        if self.attn_bf16x6 and E <= 256 and F_ <= 208:
+            # EXPERIMENTAL (GZSL_ATTN_BF16X6=1): fp32 products from six bf16 MFMAs each (csrc/attn_bf16.hip)
+            n = hip.load().gzsl_label_attn_fwd_bf16x6_work_bytes(B, Tp, E, F_)
+            work = torch.empty(n, dtype=torch.uint8, device=PX.device)
+            call('gzsl_label_attn_fwd_bf16x6', ptr(PX), ptr(X), ptr(Q), ptr(O), ptr(lse), B, Tp, E, F_, L, l_offset,
+                 L_total, seed & 0xFFFFFFFF, th, sc, ptr(work), n)
+            return O, lse
         call('gzsl_label_attn_fwd', ptr(PX), ptr(X), ptr(Q), ptr(O), ptr(lse), B, Tp, E, F_, L, l_offset, L_total,
              seed & 0xFFFFFFFF, th, sc)
         return O, lse

@@ -61,6 +61,15 @@ int gzsl_splitk_reduce(const float* slab, long long slab_stride, int nsplit, flo
 int gzsl_label_attn_fwd(const float* PX, const float* X, const float* Q, float* O, float* LSE, int B, int Tp, int E,
                         int F, int L, int l_offset, int L_total, uint32_t seed, uint32_t drop_thresh, float drop_scale,
                         void* stream);
+/* EXPERIMENTAL, opt-in (never the default path): the same forward with every fp32 product formed on the bf16 matrix pipe
+ * from three-way bf16 splits of both operands (six cross terms, fp32 accumulation; csrc/attn_bf16.hip states the error
+ * analysis, tools/bf16_split_gemm.hip measures it).  Same arguments and results (same tolerances in the tests) as
+ * gzsl_label_attn_fwd; E <= 256, F <= 208; `work` = 16-byte aligned device scratch of at least
+ * gzsl_label_attn_fwd_bf16x6_work_bytes(B, Tp, E, F) bytes (the repacked key / value tiles: 80 MB at cfg2). */
+long long gzsl_label_attn_fwd_bf16x6_work_bytes(int B, int Tp, int E, int F);
+int gzsl_label_attn_fwd_bf16x6(const float* PX, const float* X, const float* Q, float* O, float* LSE, int B, int Tp, int E,
+                               int F, int L, int l_offset, int L_total, uint32_t seed, uint32_t drop_thresh,
+                               float drop_scale, void* work, long long work_bytes, void* stream);
 /* delta[row] = sum_f dO[row,f] * O[row,f] (softmax-backward row constant), rows = B*L */
 int gzsl_attn_delta(const float* dO, const float* O, float* delta, long long rows, int F, void* stream);
 /* autograd of the above: dPX [B,Tp,E], dX [B,Tp,F], dQ [L,E] are ACCUMULATED with float atomics (caller zeroes or

@@ -237,6 +237,25 @@ ATTN_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize('B,Tp,E,F,L', ATTN_SHAPES + [(2, 2491, 100, 200, 140)])
+@pytest.mark.parametrize('p', [0.0, 0.2])
+def test_label_attention_fwd_bf16x6_experimental(ref, B, Tp, E, F, L, p):
+    """The opt-in forward (GZSL_ATTN_BF16X6=1: fp32 products as six bf16 MFMAs, csrc/attn_bf16.hip) at the SAME
+    tolerances as the fp32-MFMA kernel, incl. one full-length note."""
+    from gzsl_text_amd.ops_hip import HipOps
+    ops = HipOps()
+    ops.attn_bf16x6 = True
+    rs = np.random.RandomState(B * 1000 + Tp + L)
+    PX = torch.tanh(rnd(rs, B, Tp, E))
+    X = torch.relu(rnd(rs, B, Tp, F))
+    Q = rnd(rs, L, E, scale=0.3)
+    l_off, L_tot, seed = 5, L + 9, 4321
+    O, lse = ops.attn_fwd(g(PX), g(X), g(Q), l_off, L_tot, seed, p)
+    Or, lser = ref.attn_fwd(PX, X, Q, l_off, L_tot, seed, p)
+    close(lse, lser, 1e-5, 1e-5, 'attention log-sum-exp (bf16x6)')
+    close(O, Or, 2e-5, 2e-5, 'attention output (bf16x6)')
+
+
 @pytest.mark.parametrize('B,Tp,E,F,L', ATTN_SHAPES)
 @pytest.mark.parametrize('p', [0.0, 0.2])
 def test_label_attention_fwd_bwd(ops, ref, B, Tp, E, F, L, p):
