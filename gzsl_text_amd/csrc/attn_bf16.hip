@@ -275,13 +275,15 @@ __global__ __launch_bounds__(BF_WAVES * 64) void label_attn_fwd_bf16_kernel(Attn
 #pragma unroll
                 for (int p = 0; p < 3; ++p) va[slot][p] = *reinterpret_cast<const bf16x8*>(vrow + p * T::PLV);
             };
-            ldv(0, 0);
+            constexpr bool AHEAD = EKS <= 4;
+            if (AHEAD) ldv(0, 0);
 #pragma unroll
             for (int j = 0; j < NFT; ++j) {
-                if (j + 1 < NFT) ldv(j + 1, (j + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[j] = mfma_x6(va[j & 1], pb, acc[j]);
-                __builtin_amdgcn_sched_barrier(0);
+                if (!AHEAD) ldv(j, 0);
+                else if (j + 1 < NFT) ldv(j + 1, (j + 1) & 1);
+                if (AHEAD) __builtin_amdgcn_sched_barrier(0);
+                acc[j] = mfma_x6(va[AHEAD ? (j & 1) : 0], pb, acc[j]);
+                if (AHEAD) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();  // tile t consumed by every wave (and, with two buffers, tile t+1 stored by every wave)
