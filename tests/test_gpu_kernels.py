@@ -256,6 +256,40 @@ def test_label_attention_fwd_bf16x6_experimental(ref, B, Tp, E, F, L, p):
     close(O, Or, 2e-5, 2e-5, 'attention output (bf16x6)')
 
 
+@pytest.mark.parametrize('kind', ['peaky', 'wide_range', 'tiny_and_huge'])
+def test_label_attention_fwd_bf16x6_error_against_fp64(kind):
+    """The six-product form must be as close to an fp64 evaluation as the exact-fp32 MFMA kernel is, on inputs chosen to
+    hurt a reduced-precision product: scores up to +-60 (softmax weight on a handful of tokens), values spanning nine
+    decades, operands with very small and very large magnitudes side by side.  Dropout off (the mask is exact)."""
+    from gzsl_text_amd.ops_hip import HipOps
+    rs = np.random.RandomState({'peaky': 1, 'wide_range': 2, 'tiny_and_huge': 3}[kind])
+    B, Tp, E, F, L = 2, 333, 100, 200, 130
+    PX = torch.tanh(rnd(rs, B, Tp, E))
+    X = torch.relu(rnd(rs, B, Tp, F))
+    Q = rnd(rs, L, E, scale=0.3)
+    if kind == 'peaky':
+        Q = Q * 20.0
+    elif kind == 'wide_range':
+        X = X * torch.from_numpy(10.0 ** rs.uniform(-6, 3, size=(B, Tp, 1)).astype(np.float32))
+    else:
+        PX = PX * torch.from_numpy(10.0 ** rs.uniform(-4, 0, size=(1, 1, E)).astype(np.float32))
+        Q = Q * torch.from_numpy(10.0 ** rs.uniform(0, 3, size=(1, E)).astype(np.float32)) * 0.05
+        X = X * 1e4 + 1e-3
+    S = torch.einsum('le,bte->blt', Q.double(), PX.double())
+    lse64 = torch.logsumexp(S, dim=2)
+    O64 = torch.einsum('blt,btf->blf', torch.softmax(S, dim=2), X.double())
+    errs = {}
+    for name, flag in (('fp32', False), ('bf16x6', True)):
+        ops = HipOps()
+        ops.attn_bf16x6 = flag
+        O, lse = ops.attn_fwd(g(PX), g(X), g(Q), 0, L, 1, 0.0)
+        errs[name] = (float((O.double().cpu() - O64).abs().max() / O64.abs().max()),
+                      float((lse.double().cpu() - lse64).abs().max()))
+    # same order of error as the fp32 kernel (both accumulate in fp32; what differs is the order and the dropped 2^-24 terms)
+    assert errs['bf16x6'][0] <= 2.0 * errs['fp32'][0] + 2e-7, errs
+    assert errs['bf16x6'][1] <= 2.0 * errs['fp32'][1] + 2e-6, errs
+
+
 @pytest.mark.parametrize('B,Tp,E,F,L', ATTN_SHAPES)
 @pytest.mark.parametrize('p', [0.0, 0.2])
 def test_label_attention_fwd_bwd(ops, ref, B, Tp, E, F, L, p):
