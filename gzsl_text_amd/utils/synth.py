@@ -134,6 +134,26 @@ BASE_CASES = {
 }
 DROP_SEED = 1234
 
+# ConvLabelAttnGAN.forward in TRAIN mode (finetune.py:258,271: both dropouts live): base-case kwargs + the size of the
+# `label_indices` subset.  'e200' is the width the drivers build (E = H = 200, D = 400) at T' = 291.
+GAN_TRAIN_CASES = {
+    'tiny': dict(base=dict(seed=0, B=3, T=40, E=8, H=8, L=12, N=20, Td=6, V=50, F=24), n_sub=5),
+    'e200': dict(base=dict(seed=5, B=2, T=300, E=200, H=200, L=256, N=300, Td=8, V=400, F=200, labels_per_note=8),
+                 n_sub=37),
+}
+
+
+def gan_train_inputs(name):
+    """(case, fc0 [N,D], sub int64 [n_sub]) of a GAN_TRAIN_CASES entry: the classifier table and the label subset are
+    seeded here (not derived from reference outputs), so tests regenerate them."""
+    spec = GAN_TRAIN_CASES[name]
+    case = synth_base(**spec['base'])
+    d = case['dims']
+    rs = np.random.RandomState(1000 + spec['base']['seed'])
+    fc0 = (rs.standard_normal((d['N'], d['D'])) * 0.15).astype(np.float32)
+    sub = rs.choice(d['L'], size=spec['n_sub'], replace=False).astype(np.int64)  # unsorted, as finetune.py's syn_indices
+    return case, fc0, sub
+
 
 def build_model(case, cls=None, device='cpu', ops=None, sparse=True, C=2.0):
     """Construct the module mirror exactly as train_base.py:76-84 does and load the case's parameters."""

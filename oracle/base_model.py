@@ -344,8 +344,12 @@ def base_forward_backward(p, bufs, x, y, mask, L, margin, C, graph_encoder='gate
     return out
 
 
-def gan_model_forward_backward(p, frozen_avg, x, y, mask, L, margin, C, label_indices=None, need_grad=True):
-    """ConvLabelAttnGAN.forward (icd_modules.py:251-282), eval-mode dropout, only output_fc trainable."""
+def gan_model_forward_backward(p, frozen_avg, x, y, mask, L, margin, C, label_indices=None, need_grad=True,
+                               drop_seed=None):
+    """ConvLabelAttnGAN.forward (icd_modules.py:251-282), only output_fc trainable.  drop_seed=None: eval mode;
+    otherwise train mode as finetune.py:258,271 runs it -- embedding dropout (icd_modules.py:157) and attention dropout
+    (:140) from the counter RNG, the attention mask keyed on the rows of the ATTENDED list (a gathered subset is numbered
+    0 .. |sub|-1: the reference draws a fresh [B, |sub|, T'] mask there)."""
     fc = p['output_fc.weight']
     Q = frozen_avg
     if label_indices is not None:
@@ -355,10 +359,10 @@ def gan_model_forward_backward(p, frozen_avg, x, y, mask, L, margin, C, label_in
         rows = fc[label_indices]
     else:
         rows = fc
-    X, PX, _ = encoder_fwd(p, x, mask, None)
+    X, PX, _ = encoder_fwd(p, x, mask, drop_seed)
     Q = Q[:L]
     rows = rows[:L]
-    O, _, _ = label_attn_fwd(PX, X, Q)
+    O, _, _ = label_attn_fwd(PX, X, Q, drop_seed, l_offset=0, L_total=Q.shape[0])
     logits, loss, cc = classifier_loss_fwd(O, p['output_proj.weight'], p['output_proj.bias'], rows, y,
                                            None if margin is None else margin[:L], C)
     dfc = None

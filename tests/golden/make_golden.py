@@ -159,6 +159,41 @@ def capture_gan_model():
     print('wrote', fn, f'{os.path.getsize(fn) / 1e6:.2f} MB')
 
 
+def capture_gan_model_train(name):
+    """ConvLabelAttnGAN.forward in TRAIN mode, as finetune.py:258,271 calls it (model.train(); forward(x, y, mask,
+    label_indices=syn_indices)): both dropouts live, replaced on the reference module by the build's counter masks.  The
+    attention mask is keyed on row = note * (number of attended labels) + (row of the attended list): for a gathered
+    subset the rows are numbered locally, 0 .. |sub|-1 -- the reference draws a fresh mask of that [B, |sub|, T'] shape.
+    The first forward (full list) uses seed DROP_SEED, the second (subset) DROP_SEED + 1: one seed per training forward."""
+    case, fc0, sub = synth.gan_train_inputs(name)
+    model = build_reference_base(case, cls=ConvLabelAttnGAN)
+    model.load_pretrained_state_dict({k: torch.from_numpy(v.copy()) for k, v in case['params'].items()})
+    model.init_output_fc(torch.from_numpy(fc0))
+    model.train()
+    seed = [synth.DROP_SEED]
+    model.emb_drop = InjectedMask(lambda s: torch.from_numpy(rng.emb_dropout_scale(seed[0], s[0], s[1], s[2], 0.5)))
+    model.attn_drop = InjectedMask(lambda s: torch.from_numpy(
+        rng.attn_dropout_scale(seed[0], np.arange(s[0]), np.arange(s[1]), s[1], np.arange(s[2]), 0.2)))
+    x, y, mask = (torch.from_numpy(case[k]) for k in ('x', 'y', 'mask'))
+    out = dict(input_checksum=synth.checksum(*[case['params'][k] for k in sorted(case['params'])], case['x'], case['y'],
+                                             case['mask'], fc0, sub))
+    model.zero_grad()
+    logits, loss = model(x, y, mask)
+    loss.backward()
+    out.update(full_logits=logits.detach().numpy(), full_loss=np.float32(loss.item()),
+               full_dfc=model.output_fc.weight.grad.numpy().copy())
+    seed[0] = synth.DROP_SEED + 1
+    model.zero_grad()
+    logits, loss = model(x, y, mask, label_indices=torch.from_numpy(sub))
+    loss.backward()
+    dfc = model.output_fc.weight.grad.numpy()
+    assert not np.delete(dfc, sub, axis=0).any()   # only the subset's rows receive gradient
+    out.update(sub_logits=logits.detach().numpy(), sub_loss=np.float32(loss.item()), sub_dfc_rows=dfc[sub].copy())
+    fn = os.path.join(HERE, f'gan_model_train_{name}.npz')
+    np.savez_compressed(fn, **out)
+    print('wrote', fn, f'{os.path.getsize(fn) / 1e6:.2f} MB', 'full', out['full_loss'], 'sub', out['sub_loss'])
+
+
 def capture_gan_step(name, seed, n_iters, store_inputs, **dims):
     """One WGAN-GP step in the call order of train_gan.py:223-308 (critic x n_iters, generator x 1)."""
     s = synth.synth_gan(seed, n_iters=n_iters, **dims)
@@ -275,6 +310,10 @@ def capture_label_rnn():
 if __name__ == '__main__':
     torch.manual_seed(0)
     only = sys.argv[1:]   # `make_golden.py base_gate_e200` captures just the named base cases
+    if only == ['gan_model_train']:
+        for name in synth.GAN_TRAIN_CASES:
+            capture_gan_model_train(name)
+        sys.exit(0)
     for name, kw in synth.BASE_CASES.items():
         if only and name not in only:
             continue
@@ -284,6 +323,8 @@ if __name__ == '__main__':
         sys.exit(0)
     if not only:
         capture_gan_model()
+        for name in synth.GAN_TRAIN_CASES:
+            capture_gan_model_train(name)
     capture_gan_step('gan_step_tiny', seed=11, n_iters=5, store_inputs=True,
                      Bg=6, D=16, Ls=16, ngh=24, ndh=20, E=8, Vk=30, top_k=5)
     capture_gan_step('gan_step_medium', seed=12, n_iters=2, store_inputs=False,

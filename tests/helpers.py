@@ -43,3 +43,34 @@ def check_base_against_golden(model, case, g, train, device='cpu', grad_atol=Non
     atol = grad_atol if grad_atol is not None else (2e-6 if d['T'] > 64 else 1e-6)
     for k, p in model.named_parameters():
         close(p.grad, g['grad.' + k], 1e-4, atol, 'grad ' + k)
+
+
+def check_gan_variant_train_mode(name, g, device='cpu', ops=None):
+    """ConvLabelAttnGAN.forward in train mode as finetune.py:258,271 calls it: full label list (seed DROP_SEED), then a
+    label_indices subset (the next training forward: DROP_SEED + 1).  logits / loss rtol 1e-5, output_fc gradient rtol
+    1e-4 (the tolerances of the eval-mode golden)."""
+    case, fc0, sub = synth.gan_train_inputs(name)
+    model = build_model(case, cls=ConvLabelAttnGAN, device=device, ops=ops)
+    model.load_pretrained_state_dict({k: torch.from_numpy(v.copy()).to(device) for k, v in case['params'].items()})
+    model.init_output_fc(torch.from_numpy(fc0).to(device))
+    x, y, mask = batch_tensors(case, device)
+    model.train()
+    model.set_dropout_seed(synth.DROP_SEED)
+    model.zero_grad()
+    logits, loss = model(x, y, mask)
+    loss.backward()
+    close(logits, g['full_logits'], 1e-5, 2e-5, 'train-mode full logits')
+    close(loss, g['full_loss'], 1e-5, 1e-5, 'train-mode full loss')
+    close(model.output_fc.weight.grad, g['full_dfc'], 1e-4, 2e-6, 'train-mode full dfc')
+    model.zero_grad()
+    sub_t = torch.from_numpy(sub).to(device)
+    logits, loss = model(x, y, mask, label_indices=sub_t)
+    loss.backward()
+    close(logits, g['sub_logits'], 1e-5, 2e-5, 'train-mode subset logits')
+    close(loss, g['sub_loss'], 1e-5, 1e-5, 'train-mode subset loss')
+    dfc = model.output_fc.weight.grad
+    close(dfc[sub_t], g['sub_dfc_rows'], 1e-4, 2e-6, 'train-mode subset dfc rows')
+    rest = torch.ones(dfc.shape[0], dtype=torch.bool, device=dfc.device)
+    rest[sub_t] = False
+    assert not bool(dfc[rest].any()), 'rows outside label_indices must receive no gradient'
+    return model

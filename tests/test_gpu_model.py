@@ -60,6 +60,12 @@ def test_gan_variant_matches_reference_golden():
         helpers.close(model.output_fc.weight, g[f'ff_fc_after{step}'], 1e-5, 1e-6, f'AdamW params after {step}')
 
 
+@pytest.mark.parametrize('name', list(synth.GAN_TRAIN_CASES))
+def test_gan_variant_train_mode_matches_reference_golden(name):
+    """finetune.py:258,271 on the HIP kernels: model.train(), forward(x, y, mask[, label_indices]) with both dropouts."""
+    helpers.check_gan_variant_train_mode(name, load_golden('gan_model_train_' + name), device=DEV)
+
+
 @pytest.mark.parametrize('name', ['gan_step_tiny', 'gan_step_medium'])
 def test_wgan_gp_step_matches_reference_golden(name):
     from gzsl_text_amd.ops_hip import HipOps

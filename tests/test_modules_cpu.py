@@ -91,6 +91,11 @@ def test_gan_variant_matches_reference():
         helpers.close(model.output_fc.weight, g[f'ff_fc_after{step}'], 1e-5, 1e-6, f'AdamW params after {step}')
 
 
+@pytest.mark.parametrize('name', list(synth.GAN_TRAIN_CASES))
+def test_gan_variant_train_mode_matches_reference(name):
+    helpers.check_gan_variant_train_mode(name, load_golden('gan_model_train_' + name), ops=CpuOps())
+
+
 def test_pointer_helper_rejects_tensor_on_another_device(monkeypatch):
     """launches go to the CURRENT device's stream, so a tensor living on another device must raise instead
     of being dereferenced by the wrong GPU.  No GPU here: stand-in tensor objects + a patched current device."""

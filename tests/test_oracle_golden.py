@@ -93,6 +93,31 @@ def test_gan_model_variant_matches_reference():
         _close(fc, g[f'ff_fc_after{step}'], 1e-5, 1e-6, f'AdamW params after {step}')
 
 
+@pytest.mark.parametrize('name', list(synth.GAN_TRAIN_CASES))
+def test_gan_model_variant_train_mode_matches_reference(name):
+    """finetune.py:258,271: ConvLabelAttnGAN.forward in train mode (both dropouts), full list then a label subset."""
+    g = load_golden('gan_model_train_' + name)
+    case, fc0, sub = synth.gan_train_inputs(name)
+    assert np.isclose(synth.checksum(*[case['params'][k] for k in sorted(case['params'])], case['x'], case['y'],
+                                     case['mask'], fc0, sub), g['input_checksum'], rtol=1e-12)
+    d = case['dims']
+    p = dict(case['params'])
+    p['output_fc.weight'] = fc0
+    margin = om.class_margin_from_count(case['target_count'])
+    avg, _, _ = om.label_embedding_fwd(p, case['bufs'])
+    full = om.gan_model_forward_backward(p, avg, case['x'], case['y'], case['mask'], d['L'], margin, 2.0,
+                                         drop_seed=synth.DROP_SEED)
+    _close(full['logits'], g['full_logits'], 1e-5, 2e-5, 'train full logits')
+    _close(full['loss'], g['full_loss'], 1e-5, 1e-5, 'train full loss')
+    _close(full['dfc'], g['full_dfc'], 1e-4, 1e-6, 'train full dfc')
+    part = om.gan_model_forward_backward(p, avg, case['x'], case['y'], case['mask'], d['L'], margin, 2.0,
+                                         label_indices=sub, drop_seed=synth.DROP_SEED + 1)
+    _close(part['logits'], g['sub_logits'], 1e-5, 2e-5, 'train subset logits')
+    _close(part['loss'], g['sub_loss'], 1e-5, 1e-5, 'train subset loss')
+    _close(part['dfc'][sub], g['sub_dfc_rows'], 1e-4, 1e-6, 'train subset dfc rows')
+    assert not np.delete(part['dfc'], sub, axis=0).any()
+
+
 from tests.gan_checks import GAN_DIMS, _close_adam  # noqa: E402  (Adam-aware parameter comparison, explicit mask)
 
 
