@@ -19,6 +19,8 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                 pass), achieved GB/s of every HBM-bound kernel of the step (`hbm`, separate short pass; algorithmic
                 bytes as SURVEY.md 8d / DESIGN.md 4 state them, peak 8 TB/s) and forward-only eval scoring of the
                 same batch (`eval_forward`)
+                and the WGAN-GP step of configs[3] (`gan_step`: Bg = 8 as a HIP graph, 4096, 16384; samples/s, launches,
+                executed-GEMM-FLOP fraction of the fp32 matrix peak, numpy-oracle CPU leg at Bg = 4096)
   cpu_baseline  (N=1) the numpy oracle timed on the host cores on a bounded sample of the same workload
   comm          (N>1) per collective: ms per step the launching stream sat blocked on it (exposed communication) and
                 bytes per call; plus ms/step of a short pass with the own-notes-first ordering switched the other way.
@@ -72,7 +74,7 @@ def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json,
     newest round first: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this script).  FETCH_SIZE is doubled as
     MI355X_MICROARCH.md prescribes for gfx950; None when no measurement is committed (bench.py cannot run the profiler)."""
-    for rnd in ('r02', 'r01'):
+    for rnd in ('r03', 'r02', 'r01'):
         fn = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_traffic.json')
         try:
             with open(fn) as f:
@@ -308,6 +310,112 @@ def real_e200_pass(args, dev, steps=5):
             'whole_step_frac': step_flops(d, d['B']) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
 
+GAN_REF_FLOPS_PER_SAMPLE = 7.8e7  # the REFERENCE's count (incl. the double backward of its gradient penalty)
+
+
+def gan_cpu_baseline(case, n_iters, reg_ratio):
+    """oracle/gan.py (numpy) on the host cores: ONE full WGAN-GP step (5 critic iterations + Adam, 1 generator iteration
+    + Adam) on the same Bg = 4096 batch the GPU leg runs."""
+    from oracle import gan as og
+    d = {k: v.copy() for k, v in case['d'].items()}
+    gen = {k: v.copy() for k, v in case['g'].items()}
+    kwp = {k: v.copy() for k, v in case['kw'].items()}
+    dstate = {k: {} for k in d}
+    t0 = time.perf_counter()
+    for it in range(n_iters):
+        I = case['iters'][it]
+        _, _, grads, _ = og.critic_iteration(d, gen, I['real'], I['lab'], I['noise'], I['alpha'], I['sim'])
+        for k in d:
+            d[k] = og.adam_step(d[k], grads[k], dstate[k], 1e-4)
+    I = case['iters'][n_iters]
+    _, _, gg, kg, _ = og.generator_iteration(d, gen, kwp, I['lab'], I['noise'], I['sim'], case['kw_idx'], case['kw_mask'],
+                                            reg_ratio)
+    for k in gen:
+        gen[k] = og.adam_step(gen[k], gg[k], {}, 1e-4)
+    for k in kg:
+        kwp[k] = og.adam_step(kwp[k], kg[k], {}, 1e-4)
+    dt = time.perf_counter() - t0
+    Bg = case['dims']['Bg']
+    threads = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
+    return {'value': Bg / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'sample': f'1 full step (5 critic + 1 generator iteration, Adam) at Bg={Bg}, numpy fp32 oracle, {dt:.2f} s'}
+
+
+def gan_step_pass(dev, cpu_leg=True, bgs=(8, 4096, 16384), steps=20):
+    """The WGAN-GP step of BASELINE configs[3] (train_gan.py:223-308: 5 critic iterations + 1 generator iteration, Adam
+    lr 1e-4 betas .5/.999, keyword head top_k=20 Vk=4096 reg_ratio 0.01, add-zero similarity weights; D=400, Ls=noise=400,
+    ngh=ndh=800) on the whole-iteration engine (gan_engine.WganGpStep.full_step), inputs resident in HBM.  Bg=8 is the
+    drivers' default batch (config.py:42), replayed as ONE HIP graph; 4096 / 16384 are "large batch".  `frac` divides the
+    GEMM FLOPs the engine EXECUTES (2MNK summed over its gzsl_gemm launches of one step, counted at the C ABI) by the
+    step time and the fp32 matrix peak; the reference-count figure (7.8e7 FLOP/sample, which includes a double backward
+    the closed-form penalty never runs) is stated beside it, not instead."""
+    from gzsl_text_amd import ops_hip
+    from gzsl_text_amd.gan_engine import WganGpStep, graphed_step
+    from gzsl_text_amd.ops_hip import HipOps
+    from gzsl_text_amd.utils import synth
+    n_iters, reg_ratio = 5, 0.01
+    out = {}
+    for Bg in bgs:
+        case = synth.synth_gan(seed=7, Bg=Bg, D=400, Ls=400, ngh=800, ndh=800, E=200, Vk=4096, top_k=20, n_iters=n_iters)
+
+        def dv(dd):
+            return {k: torch.from_numpy(v).to(dev) for k, v in dd.items()}
+
+        graph = Bg <= 32
+        step = WganGpStep(HipOps(), dv(case['g']), dv(case['d']), dv(case['kw']), lr=1e-4, critic_iters=n_iters,
+                          reg_ratio=reg_ratio, capturable=graph)
+        its = [{k: torch.from_numpy(v).to(dev) for k, v in it.items()} for it in case['iters']]
+        kw_idx, kw_mask = torch.from_numpy(case['kw_idx']).to(dev), torch.from_numpy(case['kw_mask']).to(dev)
+        cb = [(it['real'], it['lab'], it['noise'], it['alpha'], it['sim']) for it in its[:n_iters]]
+        gb = (its[n_iters]['lab'], its[n_iters]['noise'], its[n_iters]['sim'], kw_idx, kw_mask)
+
+        def one():
+            return step.full_step(cb, gb)[1][0]
+
+        one()  # lazily created state
+        # count one eager step at the C ABI: launches, and the FLOPs of its GEMMs
+        orig_call, cnt = ops_hip.call, {'launches': 0, 'gemm_flops': 0.0, 'gemms': 0}
+
+        def call(name, *a):
+            cnt['launches'] += 1
+            if name == 'gzsl_gemm':
+                g = a[0]
+                cnt['gemms'] += 1
+                cnt['gemm_flops'] += 2.0 * g.M * g.N * g.K
+            return orig_call(name, *a)
+        ops_hip.call = call
+        try:
+            one()
+        finally:
+            ops_hip.call = orig_call
+        fn = graphed_step(one) if graph else one
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        n = steps * (10 if graph else 1)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g_cost = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        assert bool(torch.isfinite(g_cost))
+        line = {'samples_per_s': Bg / dt, 'ms_per_step': dt * 1e3, 'hip_graph': graph, 'steps': n,
+                'c_abi_launches_per_step': cnt['launches'], 'gemm_launches_per_step': cnt['gemms'],
+                'executed_gemm_flops_per_step': cnt['gemm_flops'],
+                'achieved': cnt['gemm_flops'] / dt / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': cnt['gemm_flops'] / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                'reference_count_flops_per_step': GAN_REF_FLOPS_PER_SAMPLE * Bg,
+                'frac_on_reference_count': GAN_REF_FLOPS_PER_SAMPLE * Bg / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+        if cpu_leg and Bg == 4096:
+            line['cpu_baseline'] = gan_cpu_baseline(case, n_iters, reg_ratio)
+        out[f'Bg{Bg}'] = line
+        del step, its, cb, gb
+        torch.cuda.empty_cache()
+    out['config'] = ('BASELINE.json configs[3]: one WGAN-GP step = 5 critic + 1 generator iteration with Adam, keyword head '
+                     '(top_k=20, Vk=4096, reg_ratio=0.01), add-zero sim weights, D=400, Ls=noise=400, ngh=ndh=800; f32')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -487,6 +595,7 @@ def main():
                 del model, opt
                 torch.cuda.empty_cache()
                 out['roofline']['also']['real_e200'] = real_e200_pass(args, dev)
+                out['roofline']['also']['gan_step'] = gan_step_pass(dev, cpu_leg=not args.no_cpu_baseline)
         except Exception as exc:  # noqa: BLE001  (the post-passes never take the headline line down)
             out['roofline']['also']['extras_error'] = repr(exc)
     if rank == 0:

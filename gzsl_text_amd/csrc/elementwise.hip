@@ -1061,11 +1061,19 @@ static __device__ __align__(256) float gz_colsum_scratch[GZ_SCRATCH_FLOATS];
 static float* g_scratch_ptr[GZ_MAX_DEVICES];  // per device; written once under g_scratch_mu
 static std::mutex g_scratch_mu;
 
-static int scratch_for_current_device(float** out) {
+// The scratch array is looked up for the CURRENT device; the kernels run on `st`'s device.  A stream of another device
+// would hand the kernels a foreign GPU's scratch address: refuse (the null stream always belongs to the current device).
+static int scratch_for_current_device(float** out, hipStream_t st) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= GZ_MAX_DEVICES) return GZSL_EINVAL;
+    if (st) {
+        int sdev = -1;
+        e = hipStreamGetDevice(st, &sdev);
+        if (e != hipSuccess) return (int)e;
+        if (sdev != dev) return GZSL_EINVAL;
+    }
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
         float* p = nullptr;
@@ -1082,7 +1090,7 @@ extern "C" int gzsl_colsum_static(const float* x, float* out, long long M, int N
     if (M <= 0 || N <= 0) return 0;
     if (N > GZSL_COLSUM_STATIC_MAX_N) return GZSL_ETOOBIG;
     float* work = nullptr;
-    const int rc = scratch_for_current_device(&work);
+    const int rc = scratch_for_current_device(&work, ST);
     if (rc != 0) return rc;
     // every partial-sum word the finish kernel reads is written by this call's first kernel: nothing to clear
     return colsum_launch(x, out, M, N, ld, work, GZ_SCRATCH_FLOATS, ST);

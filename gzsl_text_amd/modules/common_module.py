@@ -70,8 +70,10 @@ class EmbLayer(nn.Module):
         self.embed.weight.requires_grad_(not freeze_emb)
 
     def forward(self, x):
-        from ..ops_hip import HipOps
-        return HipOps().emb_gather(self.embed.weight.detach(), x.contiguous(), None, 0, 0.0)
+        if getattr(self, '_ops', None) is None:
+            from ..ops_hip import HipOps
+            self._ops = HipOps()   # one provider per module, not per call
+        return self._ops.emb_gather(self.embed.weight.detach(), x.contiguous(), None, 0, 0.0)
 
 
 class AdamW(Optimizer):

@@ -12,10 +12,12 @@ from ..engine import BaseEngine, GraphBuffers
 
 
 def _standalone(kind, module, x, adj_matrix, num_neighbors, prefix):
-    from ..ops_hip import HipOps
     if x.dim() != 2:
         raise NotImplementedError('only the 2-D (label) branch is on the hot path (graph_module.py:61,105)')
-    eng = BaseEngine(HipOps(), graph_encoder=kind, steps=getattr(module, 'steps', 2))
+    if getattr(module, '_ops', None) is None:
+        from ..ops_hip import HipOps
+        module._ops = HipOps()   # one provider per module, not per call
+    eng = BaseEngine(module._ops, graph_encoder=kind, steps=getattr(module, 'steps', 2))
     P = {prefix + k: v.detach() for k, v in module.named_parameters()}
     gb = GraphBuffers.__new__(GraphBuffers)
     from ..engine import build_csr, EPS_DEG

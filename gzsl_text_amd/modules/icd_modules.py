@@ -407,6 +407,11 @@ class _GanModelFn(torch.autograd.Function):
         else:
             X, PX, _ = eng.encoder_fwd(P, x, mask_c, seed, training)
         if sh is not None:
+            # same errors as the unsharded path (HipOps.ldam_bce's shape checks) before the columns are cut per rank
+            if y.shape[1] != Lp:
+                raise RuntimeError(f'ldam_bce: targets {tuple(y.shape)} do not match logits {(B, Lp)}')
+            if margin is not None and margin.numel() != Lp:
+                raise RuntimeError(f'ldam_bce: {margin.numel()} margins for {Lp} labels')
             Q, clf = Q[l0:l1].contiguous(), clf[l0:l1].contiguous()
             y = y[:, l0:l1]
             if margin is not None:
@@ -475,9 +480,6 @@ class ConvLabelAttnGAN(ConvLabelAttnModel):
         self.name = 'gan_' + self.name
         self.output_fc = nn.Linear(self.feat_size, self.code_idx_matrix.size(0), bias=False)
         nn.init.xavier_uniform_(self.output_fc.weight)
-
-    def _param_names(self):
-        return [k for k in super()._param_names()]
 
     def update_class_margin(self, target_count, C):
         assert self.class_margin is not None and self.C > 0

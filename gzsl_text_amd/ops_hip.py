@@ -26,21 +26,51 @@ def _check_f32(*ts):
             raise RuntimeError(f'expected float32 tensor, got {t.dtype}')
 
 
+_DETERMINISTIC = False
+
+
+def set_deterministic(on):
+    """The deterministic-reduction mode is PROCESS-WIDE: it sets the library's switch (gzsl_set_deterministic: one-block
+    loss sum, workspace column sums) and serialises the second stream (streams.Beside), and every HipOps of the process
+    then takes the slab / sorted-gather forms of the attention and embedding gradients.  Returns the previous setting."""
+    global _DETERMINISTIC
+    from .streams import Beside
+    prev = _DETERMINISTIC
+    _DETERMINISTIC = bool(on)
+    Beside.serial = _DETERMINISTIC
+    hip.load().gzsl_set_deterministic(1 if _DETERMINISTIC else 0)
+    return prev
+
+
+def det_attn_bwd_work_bytes(B, Tp, E, F, L, nsplit):
+    """Workspace of the deterministic attention backward (gzsl_label_attn_bwd_det): one [L,E] dQ slab per (note, token
+    tile of 128 (E <= 100) or 64 tokens) and one [B,Tp,E+F] slab per label split."""
+    ntt = -(-Tp // (128 if E <= 100 else 64))
+    return 4 * (B * ntt * L * E + nsplit * B * Tp * (E + F))
+
+
 class HipOps:
-    """deterministic=True (or GZSL_DETERMINISTIC=1): every cross-workgroup sum of the train step takes a fixed-order
-    form -- attention gradients through slabs + ordered reduce (gzsl_label_attn_bwd_det), the embedding gradient as a
-    gather over a sorted index instead of float atomics, loss / column sums without atomics, one stream.  Two runs on
-    the same inputs are then bit-identical (tests/test_gpu_model.py); it costs memory and ~10 % of the step."""
+    """Deterministic mode (`HipOps(deterministic=True)`, GZSL_DETERMINISTIC=1, or ops_hip.set_deterministic(True)):
+    every cross-workgroup sum of the train step takes a fixed-order form -- attention gradients through slabs + ordered
+    reduce (gzsl_label_attn_bwd_det), the embedding gradient as a gather over a sorted index instead of float atomics,
+    loss / column sums without atomics, one stream.  Two runs on the same inputs are then bit-identical
+    (tests/test_gpu_model.py); it costs memory (det_attn_bwd_work_bytes: 1.3 GB at cfg2) and ~60 % of the step.
+    The mode is process-wide (see set_deterministic): `deterministic=True` switches it on for every provider,
+    an explicit `deterministic=False` switches it off, and the default (None) follows the environment / current mode."""
     name = 'hip'
 
     def __init__(self, deterministic=None):
         import os
-        self.deterministic = (os.environ.get('GZSL_DETERMINISTIC') == '1') if deterministic is None else bool(deterministic)
+        if deterministic is None:
+            if os.environ.get('GZSL_DETERMINISTIC') == '1' and not _DETERMINISTIC:
+                set_deterministic(True)
+        else:
+            set_deterministic(bool(deterministic))
         self.attn_bf16x6 = os.environ.get('GZSL_ATTN_BF16X6') == '1'  # experimental forward attention, off by default
-        if self.deterministic:
-            from .streams import Beside
-            Beside.serial = True
-            hip.load().gzsl_set_deterministic(1)
+
+    @property
+    def deterministic(self):
+        return _DETERMINISTIC
 
     # ------------------------------------------------------------------------------------ GEMM plumbing
     @staticmethod
@@ -321,6 +351,11 @@ class HipOps:
         th, sc = drop_params(p)
         if self.deterministic:
             n = hip.load().gzsl_label_attn_bwd_det_work_floats(B, Tp, E, X.shape[2], Q.shape[0], nsplit)
+            free = torch.cuda.mem_get_info(PX.device)[0] + torch.cuda.memory_reserved(PX.device) - torch.cuda.memory_allocated(PX.device)
+            if 4 * n > free:
+                raise RuntimeError(f'deterministic attention backward needs a {4 * n / 2**30:.2f} GiB workspace '
+                                   f'(B*ceil(Tp/{128 if E <= 100 else 64})*L*E + nsplit*B*Tp*(E+F) floats; '
+                                   f'{free / 2**30:.2f} GiB free): lower the batch or the label shard')
             work = torch.empty(n, dtype=torch.float32, device=PX.device)
             call('gzsl_label_attn_bwd_det', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
                  ptr(dQ), B, Tp, E, X.shape[2], Q.shape[0], l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc,

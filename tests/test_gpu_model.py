@@ -114,7 +114,7 @@ def test_deterministic_mode_is_bit_reproducible(name):
     """HipOps(deterministic=True): attention gradients through slabs + an ordered reduce, the embedding gradient as a
     gather over a sorted index, loss / column sums without atomics, one stream.  Two train steps on the same inputs must
     agree bit for bit in loss, logits and every gradient -- and still match the reference's golden vectors."""
-    from gzsl_text_amd import hip
+    from gzsl_text_amd import ops_hip
     from gzsl_text_amd.ops_hip import HipOps
     from gzsl_text_amd.streams import Beside
     g = load_golden(f'{name}_train')
@@ -133,9 +133,10 @@ def test_deterministic_mode_is_bit_reproducible(name):
             runs.append([logits.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in model.parameters()])
         for a, b in zip(*runs):
             assert torch.equal(a, b), float((a - b).abs().max())
+        assert HipOps().deterministic      # the mode is process-wide: a provider built later inherits it ...
+        assert not HipOps(deterministic=False).deterministic and not Beside.serial   # ... and an explicit False ends it
     finally:
-        hip.load().gzsl_set_deterministic(0)
-        Beside.serial = False
+        ops_hip.set_deterministic(False)
 
 
 def test_gan_plain_wgan_step_on_hip():
