@@ -242,14 +242,19 @@ def eval_forward_pass(model, x, y, mask, d, steps=10):
             'frac_of_fp32_matrix_peak': fwd / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
 
-def bf16x6_forward_pass(model, step, ops, timer, x, y, mask, d, B, steps=20):
-    """EXPERIMENTAL switch, reported beside the headline and never part of it: the forward label attention with each
-    fp32 product formed as six bf16 MFMAs (csrc/attn_bf16.hip; inputs, outputs and accumulation stay fp32 and the
-    kernel passes the fp32 kernel's parity cases at the same tolerances).  Same step, same batch, switch on."""
+PEAK_BF16_MFMA_TFLOPS = 2516.8  # MI355X_MICROARCH.md: dense bf16 matrix peak; six bf16 products per fp32 product
+
+
+def bf16x6_step_pass(model, step, ops, timer, x, y, mask, d, B, steps=20):
+    """OPT-IN switch, reported beside the headline and never part of it (`value` / `dtype: f32` stay on the exact-fp32
+    MFMA kernels): both attention kernels with each fp32 product formed as six bf16 MFMAs (csrc/attn_bf16.hip,
+    csrc/attn_bwd_bf16.hip; inputs, outputs and accumulation stay fp32; the kernels pass the fp32 kernels' parity cases at
+    the same tolerances).  Same step, same batch, switch on.  `frac` = fp32-equivalent FLOP rate over 2516.8 / 6 TFLOP/s."""
     assert not ops.attn_bf16x6
     ops.attn_bf16x6 = True
     try:
         timer.events['attn_fwd'].clear()
+        timer.events['attn_bwd_main'].clear()
         for _ in range(2):
             loss = step()
         torch.cuda.synchronize()
@@ -260,15 +265,24 @@ def bf16x6_forward_pass(model, step, ops, timer, x, y, mask, d, B, steps=20):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         timer.enabled = False
-        fwd_ms = timer.total_ms('attn_fwd', steps)
+        fwd_ms, bwd_ms = timer.total_ms('attn_fwd', steps), timer.total_ms('attn_bwd_main', steps)
         ev = eval_forward_pass(model, x, y, mask, d)
     finally:
         timer.enabled = False
         ops.attn_bf16x6 = False
+        timer.events['attn_fwd'].clear()
+        timer.events['attn_bwd_main'].clear()
     fl = algorithmic_flops(d, B, d['L'])
-    return {'config': f'GZSL_ATTN_BF16X6=1 (forward attention only; backward unchanged); {steps} steps',
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    return {'config': f'GZSL_ATTN_BF16X6=1 (forward and backward attention as six bf16 MFMAs per fp32 product); {steps} steps',
             'ms_per_step': dt * 1e3, 'notes_per_s': B / dt, 'loss': float(loss.detach()),
-            'label_attn_fwd': {'ms_per_call_incl_repack': fwd_ms, 'fp32_equivalent_tflops': fl / (fwd_ms * 1e-3) / 1e12},
+            'peak_fp32_equivalent_tflops': peak,
+            'label_attn_fwd': {'ms_per_call_incl_repack': fwd_ms, 'fp32_equivalent_tflops': fl / (fwd_ms * 1e-3) / 1e12,
+                               'frac': fl / (fwd_ms * 1e-3) / 1e12 / peak},
+            'label_attn_bwd': {'ms_per_call_incl_repack_and_dq_reduce': bwd_ms,
+                               'fp32_equivalent_tflops': 2 * fl / (bwd_ms * 1e-3) / 1e12,
+                               'frac': 2 * fl / (bwd_ms * 1e-3) / 1e12 / peak},
+            'whole_step_frac_of_fp32_matrix_peak': step_flops(d, B) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             'eval_forward': {'ms_per_batch': ev['ms_per_batch'], 'notes_per_s': ev['notes_per_s']}}
 
 
@@ -472,7 +486,7 @@ def main():
     x, y, mask = synth.batch_tensors(case, dev)
     opt = get_optimizer(1e-3, model, weight_decay=1e-5)
     ops = model._engine().ops
-    ops.attn_bf16x6 = False  # the metric is the exact-fp32 MFMA path whatever the environment says (see bf16x6_forward_pass)
+    ops.attn_bf16x6 = False  # the metric is the exact-fp32 MFMA path whatever the environment says (see bf16x6_step_pass)
     timer = KernelTimer(ops, ['attn_fwd', 'attn_bwd_main'])  # attn_bwd_main = the label_attn_bwd launch alone
 
     def step():
@@ -590,7 +604,7 @@ def main():
         try:
             out['roofline']['also']['hbm'] = hbm_pass(model, step, ops, d, B)
             out['roofline']['also']['eval_forward'] = eval_forward_pass(model, x, y, mask, d)
-            out['roofline']['also']['experimental_fwd_bf16x6'] = bf16x6_forward_pass(model, step, ops, timer, x, y, mask, d, B)
+            out['roofline']['also']['bf16x6_step'] = bf16x6_step_pass(model, step, ops, timer, x, y, mask, d, B)
             if args.config == 'cfg2' and args.E == 100:
                 del model, opt
                 torch.cuda.empty_cache()

@@ -13,55 +13,13 @@
 // every ds_read_b128 below is conflict-free -- so staging is a flat 16-byte copy; a workgroup is 8 waves = 128 labels
 // (half the tile traffic per label of the fp32 kernel's 64); P is split into its three planes in registers.
 #include "common.h"
+#include "bf16x3.h"
 #include "rng.h"
 #include "../../include/gzsl_hip.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // (HIP's uint4 struct sent the staging array to scratch)
 
 #define BF_BT 32        // tokens per tile = k of one MFMA
 #define BF_WAVES 8      // 128 labels per workgroup
 #define BF_RESCALE 12.0f
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// two floats -> packed bf16 pair, round-to-nearest-even (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-// (a, b) = h + m + l exactly per element; each result holds the pair's pieces as packed bf16 (a low, b high)
-__device__ __forceinline__ void split3_pk(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-    h = cvt_pk(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xFFFF0000u);
-    m = cvt_pk(ra, rb);
-    l = cvt_pk(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xFFFF0000u));
-}
-// eight floats -> the three bf16x8 planes
-__device__ __forceinline__ void split3_x8(const float (&v)[8], bf16x8 (&pl)[3]) {
-    u32x4 h, m, l;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        unsigned hh, mm, ll;
-        split3_pk(v[2 * i], v[2 * i + 1], hh, mm, ll);
-        h[i] = hh, m[i] = mm, l[i] = ll;
-    }
-    pl[0] = __builtin_bit_cast(bf16x8, h);
-    pl[1] = __builtin_bit_cast(bf16x8, m);
-    pl[2] = __builtin_bit_cast(bf16x8, l);
-}
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-// c += a.b from the planes of a and b, smallest terms first
-__device__ __forceinline__ f32x4 mfma_x6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
-    c = mfma_bf16(a[2], b[0], c);
-    c = mfma_bf16(a[0], b[2], c);
-    c = mfma_bf16(a[1], b[1], c);
-    c = mfma_bf16(a[1], b[0], c);
-    c = mfma_bf16(a[0], b[1], c);
-    return mfma_bf16(a[0], b[0], c);
-}
 
 // Tile image (bytes): K planes [3][32 tokens][EK bf16], chunk c (8 e) of token row r at chunk c ^ (r & 15);
 //                     V^T planes [3][FP f][32 tokens bf16], chunk q of row f at chunk q ^ ((f >> 1) & 3), where chunk q

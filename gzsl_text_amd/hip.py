@@ -40,6 +40,8 @@ _PROTOS = {
     'gzsl_label_attn_fwd_bf16x6_work_bytes': [c_int] * 4,
     'gzsl_attn_delta': [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p],
     'gzsl_label_attn_bwd': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p],
+    'gzsl_label_attn_bwd_bf16x6': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p, c_ll, c_void_p],
+    'gzsl_label_attn_bwd_bf16x6_work_bytes': [c_int] * 5,
     'gzsl_label_attn_bwd_det': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p, c_ll, c_void_p],
     'gzsl_label_attn_bwd_det_work_floats': [c_int] * 6,
     'gzsl_set_deterministic': [c_int],
@@ -99,7 +101,8 @@ def load():
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = c_ll if name in ('gzsl_label_attn_bwd_det_work_floats', 'gzsl_label_attn_fwd_bf16x6_work_bytes') else c_int
+        fn.restype = c_ll if name in ('gzsl_label_attn_bwd_det_work_floats', 'gzsl_label_attn_fwd_bf16x6_work_bytes',
+                                        'gzsl_label_attn_bwd_bf16x6_work_bytes') else c_int
     lib.gzsl_build_info.restype = ctypes.c_char_p
     lib.gzsl_build_info.argtypes = []
     _lib = lib

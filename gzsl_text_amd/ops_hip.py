@@ -5,6 +5,8 @@ parallel.py) is written against this interface so that its orchestration -- not 
 can also be exercised on CPU by the test suite's stand-in (tests/ops_cpu.py).  Nothing here falls
 back to torch arithmetic: torch supplies device memory (empty/zeros), views and streams only.
 """
+import os
+
 import torch
 
 from . import hip
@@ -360,6 +362,19 @@ class HipOps:
             call('gzsl_label_attn_bwd_det', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
                  ptr(dQ), B, Tp, E, X.shape[2], Q.shape[0], l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc,
                  ptr(work), n)
+            return
+        if self.attn_bf16x6 and E <= 112 and X.shape[2] <= 208:
+            # opt-in (GZSL_ATTN_BF16X6=1): fp32 products from six bf16 MFMAs each (csrc/attn_bwd_bf16.hip); 64-token workgroups
+            F_, L = X.shape[2], Q.shape[0]
+            n = hip.load().gzsl_label_attn_bwd_bf16x6_work_bytes(B, Tp, E, F_, L)
+            work = torch.empty(n, dtype=torch.uint8, device=PX.device)
+            wgs = B * ((Tp + 63) // 64)
+            ns = 1
+            while wgs * ns < 1024 and ns * 2 * 32 <= L:
+                ns *= 2
+            ns = int(os.environ.get('GZSL_BB_NSPLIT', ns))  # (diagnostic override)
+            call('gzsl_label_attn_bwd_bf16x6', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
+                 ptr(dQ), B, Tp, E, F_, L, l_offset, L_total, ns, seed & 0xFFFFFFFF, th, sc, ptr(work), n)
             return
         call('gzsl_label_attn_bwd', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
              ptr(dQ), B, Tp, E, X.shape[2], Q.shape[0], l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc)

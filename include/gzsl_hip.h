@@ -78,6 +78,17 @@ int gzsl_label_attn_bwd(const float* dO, const float* PX, const float* X, const 
                         const float* DELTA, float* dPX, float* dX, float* dQ, int B, int Tp, int E, int F, int L,
                         int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh, float drop_scale,
                         void* stream);
+/* Opt-in, beside gzsl_label_attn_fwd_bf16x6: the same backward (autograd of icd_modules.py:137-142; same arguments,
+ * accumulation contract and test tolerances as gzsl_label_attn_bwd) with every fp32 product formed as six bf16 MFMAs
+ * (csrc/attn_bwd_bf16.hip).  E <= 112, F <= 208 (GZSL_EINVAL beyond: callers fall back to gzsl_label_attn_bwd); 64-token
+ * workgroups; `work` = 16-byte aligned device scratch of at least gzsl_label_attn_bwd_bf16x6_work_bytes(B, Tp, E, F, L)
+ * bytes (the bf16 plane images of Q and dO per 32-label tile, 218 MB at cfg2, and one slab of partial dQ tiles per
+ * (note, 64-token tile), 2.5 GB at cfg2, summed in a fixed order by a second launch). */
+long long gzsl_label_attn_bwd_bf16x6_work_bytes(int B, int Tp, int E, int F, int L);
+int gzsl_label_attn_bwd_bf16x6(const float* dO, const float* PX, const float* X, const float* Q, const float* LSE,
+                               const float* DELTA, float* dPX, float* dX, float* dQ, int B, int Tp, int E, int F, int L,
+                               int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh,
+                               float drop_scale, void* work, long long work_bytes, void* stream);
 
 /* Deterministic form of gzsl_label_attn_bwd (SURVEY 5 asks for a deterministic-reduction mode; the reference itself is
  * only as reproducible as torch's atomics-based embedding / index_add backward): the partial sums leave as plain stores

@@ -237,7 +237,8 @@ ATTN_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize('B,Tp,E,F,L', ATTN_SHAPES + [(2, 2491, 100, 200, 140)])
+@pytest.mark.parametrize('B,Tp,E,F,L', ATTN_SHAPES + [(2, 2491, 100, 200, 140), (2, 2491, 200, 200, 70), (1, 3991, 100, 200, 140),
+                                                   (1, 3991, 200, 200, 70)])
 @pytest.mark.parametrize('p', [0.0, 0.2])
 def test_label_attention_fwd_bf16x6_experimental(ref, B, Tp, E, F, L, p):
     """The opt-in forward (GZSL_ATTN_BF16X6=1: fp32 products as six bf16 MFMAs, csrc/attn_bf16.hip) at the SAME
