@@ -560,10 +560,23 @@ extern "C" long long gzsl_label_attn_bwd_bf16x6_work_bytes(int B, int Tp, int E,
     return bwd_bf_tile_bytes(B, L) + 4 * bwd_bf_slab_floats(B, Tp, L);
 }
 
+extern "C" int gzsl_label_attn_bwd_bf16x6_dq_reduce(const void* work, float* dQ, int B, int Tp, int E, int F, int L, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if (Tp <= 0 || !bwd_bf_supported(E, F) || !work) return GZSL_EINVAL;
+    const int nLT = cdiv(L, BB_BL), nTT = cdiv(Tp, BB_TOK);
+    const float* slab = (const float*)((const unsigned char*)work + bwd_bf_tile_bytes(B, L));
+    const long long per_slab = (long long)nLT * BwdBf::NET * 512;
+    hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       slab, dQ, B * nTT, per_slab, E, L);
+    GZSL_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gzsl_label_attn_bwd_bf16x6(const float* dO, const float* PX, const float* X, const float* Q, const float* LSE,
                                           const float* DELTA, float* dPX, float* dX, float* dQ, int B, int Tp, int E, int F,
                                           int L, int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh,
-                                          float drop_scale, void* work, long long work_bytes, void* stream) {
+                                          float drop_scale, void* work, long long work_bytes, int defer_dq_reduce,
+                                          void* stream) {
     if (B <= 0 || L <= 0) return 0;
     if (Tp <= 0 || nsplit <= 0 || !bwd_bf_supported(E, F) || !work || (((uintptr_t)work) & 15) != 0) return GZSL_EINVAL;
     const long long need = gzsl_label_attn_bwd_bf16x6_work_bytes(B, Tp, E, F, L);
@@ -583,9 +596,6 @@ extern "C" int gzsl_label_attn_bwd_bf16x6(const float* dO, const float* PX, cons
     if (drop_thresh) hipLaunchKernelGGL((label_attn_bwd_bf16_kernel<true>), grid, block, T::total, st, a);
     else hipLaunchKernelGGL((label_attn_bwd_bf16_kernel<false>), grid, block, T::total, st, a);
     GZSL_CHECK_LAUNCH();
-    const long long per_slab = (long long)nLT * T::NET * 512;
-    hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3((unsigned)((per_slab + 255) / 256)), dim3(256), 0, st, slab, dQ, B * nTT,
-                       per_slab, E, L);
-    GZSL_CHECK_LAUNCH();
-    return 0;
+    if (defer_dq_reduce) return 0;
+    return gzsl_label_attn_bwd_bf16x6_dq_reduce(work, dQ, B, Tp, E, F, L, stream);
 }

@@ -80,6 +80,24 @@ class BaseEngine:
         self.graph_encoder = graph_encoder
         self.steps = steps
 
+    def _deferring(self):
+        """While active, the bf16x6 attention backward leaves its dQ slab sum to `label_bwd` (every model backward ends
+        with one: _BaseModelFn.backward).  No effect on providers without the switch (exact-fp32 kernels, CPU stand-in)."""
+        import contextlib
+        ops = self.ops
+
+        @contextlib.contextmanager
+        def cm():
+            had = getattr(ops, 'defer_dq', None)
+            if had is not None:
+                ops.defer_dq = True
+            try:
+                yield
+            finally:
+                if had is not None:
+                    ops.defer_dq = had
+        return cm()
+
     # ------------------------------------------------------------------------------------------ label side
     def label_fwd(self, P, gb, keep=True):
         """icd_modules.py:115-123 -> avg [N,E], graph [N,D], cache."""
@@ -121,6 +139,9 @@ class BaseEngine:
         """Adds the label-side parameter gradients into G; davg / dgraph are [N,E] / [N,D] (rows past L zero)."""
         ops = self.ops
         E = davg.shape[1]
+        # deferred dQ sums of the bf16x6 attention backward (attn_bwd_block / head_bwd): added here, on the stream that
+        # runs the label side, beside the note encoder's backward (which does not read davg)
+        self._keep = getattr(ops, 'flush_pending_dq', lambda: None)()
         if self.graph_encoder == 'gate':
             pre = 'graph_label_encoder.gru.'
             dx = dgraph[:, :E].contiguous()
@@ -193,8 +214,9 @@ class BaseEngine:
     def attn_bwd_block(self, dO, O, lse, PX, X, Q, c0, c1, l_offset, L_total, seed, training, dPX, dX, dQ, delta=None):
         """Backward of `attn_fwd_block` for notes [c0, c1): adds into dPX / dX (tensors of THAT block) and dQ.
         delta [B,L]: rowsum(dO * O) of the whole batch when head_bwd_pre has produced it."""
-        self.ops.attn_bwd(dO[c0:c1], O[c0:c1], PX, X, Q, lse[c0:c1], l_offset + c0 * L_total, L_total, seed,
-                          P_ATTN_DROP if training else 0.0, dPX, dX, dQ, delta=None if delta is None else delta[c0:c1])
+        with self._deferring():
+            self.ops.attn_bwd(dO[c0:c1], O[c0:c1], PX, X, Q, lse[c0:c1], l_offset + c0 * L_total, L_total, seed,
+                              P_ATTN_DROP if training else 0.0, dPX, dX, dQ, delta=None if delta is None else delta[c0:c1])
 
     def head_fwd(self, P, X, PX, Q, clf, l_offset, L_total, seed, training, attn=None):
         """icd_modules.py:137-142,159,177-182 for the label rows [l_offset, l_offset + len(Q)).  attn = (O, lse) when
@@ -241,8 +263,9 @@ class BaseEngine:
         dclf, dO, pending, delta = self.head_bwd_pre(dlogits, O, direct, clf, P)
         if not defer_wgrad:
             self.head_wgrad(pending, G)
-        ops.attn_bwd(dO, O, PX, X, Q, lse, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0, dPX, dX, dQ,
-                     delta=delta)
+        with self._deferring():
+            ops.attn_bwd(dO, O, PX, X, Q, lse, l_offset, L_total, seed, P_ATTN_DROP if training else 0.0, dPX, dX, dQ,
+                         delta=delta)
         return (dclf, pending) if defer_wgrad else dclf
 
     def head_wgrad(self, pending, G):

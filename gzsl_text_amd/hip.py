@@ -40,7 +40,8 @@ _PROTOS = {
     'gzsl_label_attn_fwd_bf16x6_work_bytes': [c_int] * 4,
     'gzsl_attn_delta': [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p],
     'gzsl_label_attn_bwd': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p],
-    'gzsl_label_attn_bwd_bf16x6': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p, c_ll, c_void_p],
+    'gzsl_label_attn_bwd_bf16x6': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p, c_ll, c_int, c_void_p],
+    'gzsl_label_attn_bwd_bf16x6_dq_reduce': [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
     'gzsl_label_attn_bwd_bf16x6_work_bytes': [c_int] * 5,
     'gzsl_label_attn_bwd_det': [c_void_p] * 9 + [c_int] * 8 + [c_u32, c_u32, c_float, c_void_p, c_ll, c_void_p],
     'gzsl_label_attn_bwd_det_work_floats': [c_int] * 6,

@@ -68,7 +68,9 @@ class HipOps:
                 set_deterministic(True)
         else:
             set_deterministic(bool(deterministic))
-        self.attn_bf16x6 = os.environ.get('GZSL_ATTN_BF16X6') == '1'  # experimental forward attention, off by default
+        self.attn_bf16x6 = os.environ.get('GZSL_ATTN_BF16X6') == '1'  # opt-in bf16-pipe attention kernels, off by default
+        self.defer_dq = False      # set by the engine around its attention backward (bf16x6 path only)
+        self._pending_dq = []
 
     @property
     def deterministic(self):
@@ -373,11 +375,21 @@ class HipOps:
             while wgs * ns < 1024 and ns * 2 * 32 <= L:
                 ns *= 2
             ns = int(os.environ.get('GZSL_BB_NSPLIT', ns))  # (diagnostic override)
+            defer = bool(getattr(self, 'defer_dq', False))
             call('gzsl_label_attn_bwd_bf16x6', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
-                 ptr(dQ), B, Tp, E, F_, L, l_offset, L_total, ns, seed & 0xFFFFFFFF, th, sc, ptr(work), n)
+                 ptr(dQ), B, Tp, E, F_, L, l_offset, L_total, ns, seed & 0xFFFFFFFF, th, sc, ptr(work), n, int(defer))
+            if defer:  # the engine adds the dQ slabs later, on the stream that runs the label-side backward
+                self._pending_dq.append((work, dQ, (B, Tp, E, F_, L)))
             return
         call('gzsl_label_attn_bwd', ptr(dO), ptr(PX), ptr(X), ptr(Q), ptr(lse), ptr(delta), ptr(dPX), ptr(dX),
              ptr(dQ), B, Tp, E, X.shape[2], Q.shape[0], l_offset, L_total, nsplit, seed & 0xFFFFFFFF, th, sc)
+
+    def flush_pending_dq(self):
+        """Adds the dQ slabs of deferred bf16x6 attention backwards (defer_dq) on the CURRENT stream."""
+        pend, self._pending_dq = self._pending_dq, []
+        for work, dQ, dims in pend:
+            call('gzsl_label_attn_bwd_bf16x6_dq_reduce', ptr(work), ptr(dQ), *dims)
+        return pend  # the caller keeps the workspaces alive until its streams have joined
 
     def logits_fwd(self, direct, clf):
         B, L, D = direct.shape

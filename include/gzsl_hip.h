@@ -88,7 +88,11 @@ long long gzsl_label_attn_bwd_bf16x6_work_bytes(int B, int Tp, int E, int F, int
 int gzsl_label_attn_bwd_bf16x6(const float* dO, const float* PX, const float* X, const float* Q, const float* LSE,
                                const float* DELTA, float* dPX, float* dX, float* dQ, int B, int Tp, int E, int F, int L,
                                int l_offset, int L_total, int nsplit, uint32_t seed, uint32_t drop_thresh,
-                               float drop_scale, void* work, long long work_bytes, void* stream);
+                               float drop_scale, void* work, long long work_bytes, int defer_dq_reduce, void* stream);
+/* defer_dq_reduce != 0 leaves dPX / dX complete and dQ untouched: the sum of the dQ slabs in `work` is then added by this
+ * call (same B, Tp, E, F, L), on any stream ordered after the first -- e.g. beside the encoder's backward, which does
+ * not need dQ (train_base.py:112's autograd has no such split; it exists for stream overlap only). */
+int gzsl_label_attn_bwd_bf16x6_dq_reduce(const void* work, float* dQ, int B, int Tp, int E, int F, int L, void* stream);
 
 /* Deterministic form of gzsl_label_attn_bwd (SURVEY 5 asks for a deterministic-reduction mode; the reference itself is
  * only as reproducible as torch's atomics-based embedding / index_add backward): the partial sums leave as plain stores
