@@ -572,6 +572,10 @@ def main():
         out['comm'] = {'world_size_seen_by_rccl': dist.get_world_size(), 'backend': dist.get_backend(),
                        'own_notes_first': bool(model._shard.own_first),
                        'collectives': comm,
+                       # one line to read scaling off: what the launching stream waited on collectives, and what is left
+                       'exposed_ms_per_step': sum(v['exposed_ms_per_step'] for v in comm.values()),
+                       'ms_per_step_minus_exposed': dt / args.steps * 1e3 - sum(v['exposed_ms_per_step'] for v in comm.values()),
+                       'rank0_attn_fwd_ms_per_step': fwd_ms, 'rank0_attn_bwd_ms_per_step': bwd_ms * n_bwd,
                        'note': 'exposed_ms_per_step = event-timed time the launching stream sat blocked on the collective '
                                '(rank 0); no scaling curve has been measured by the builder (one-GPU boxes only)'}
         if not args.no_extras and world > 1 and model._shard.batch_split(B) is not None:

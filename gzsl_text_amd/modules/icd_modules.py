@@ -108,8 +108,7 @@ class _BaseModelFn(torch.autograd.Function):
         m_l = None if margin is None else margin[l0:l1]
         loss, dlogits, _ = eng.ops.ldam_bce(logits_l, y_l, m_l, mod.C, 1.0 / B, need_grad=need_grad)
         if sh is not None:
-            logits = sh.all_gather_labels(logits_l, L)
-            sh.all_reduce_(loss, 'loss_all_reduce')
+            logits, loss = sh.all_gather_logits_loss(logits_l, loss, L)
         else:
             logits = logits_l
         if need_grad:
@@ -422,8 +421,7 @@ class _GanModelFn(torch.autograd.Function):
         loss, dlogits, _ = eng.ops.ldam_bce(logits, y.contiguous().to(torch.float32), margin, mod.C, 1.0 / B,
                                             need_grad=need_grad)
         if sh is not None:
-            logits = sh.all_gather_labels(logits, Lp)
-            sh.all_reduce_(loss, 'loss_all_reduce')
+            logits, loss = sh.all_gather_logits_loss(logits, loss, Lp)
         if need_grad:
             ctx.mod = mod
             ctx.state = (direct, clf, dlogits, idx, fcw.shape, l0)
