@@ -59,18 +59,16 @@ struct BwdBf {
     static constexpr int OB = 3 * PLO;                   // 46080
     static constexpr int AUXB = 3 * BB_BL * 4;           // lse[32], delta[32], dropout row keys[32]
     static constexpr int TO = OB + AUXB, OCH = TO / 16;  // 46464 bytes = 2904 chunks
-    static constexpr int RK = 224, PLK = BB_TOK * RK;    // K image [64 tokens][112 e] x 3 planes (B operand of dQ)
-    static constexpr int RS = 72, PLS = BB_TOK * RS;     // dS image [64 tokens][32 labels] x 3 planes
+    static constexpr int RS = 72, PLS = BB_TOK * RS;     // dS image [64 tokens][32 labels] x 3 planes, two buffers
     static constexpr int XPD = BB_TG * 64 * 16;          // one plane of the Pd exchange (16 bytes per lane)
-    static constexpr int oQ = 0, oO = QBP, oK = oO + TO, oS = oK + 3 * PLK, oXP = oS + 3 * PLS, oXD = oXP + 3 * XPD,
-                         total = oXD + 2 * XPD;
-    // staging slots (16-byte chunks per thread and step): the 256 K-role threads (fewer persistent registers) take the Q tile
-    // (7 slots) and the first 5 x 256 chunks of the dO tile, the 256 V-role threads the remaining 1624 chunks (7 slots)
-    static constexpr int NSQ = QCH / 256, NSK = 12, OCK = (NSK - NSQ) * 256, NSV = (OCH - OCK + 255) / 256;
+    static constexpr int oQ = 0, oO = QBP, oS = oO + TO, oXP = oS + 2 * 3 * PLS, oXD = oXP + 3 * XPD, total = oXD + 2 * XPD;
+    // staging slots (16-byte chunks per thread and step): the 256 K-role threads take the Q tile (7 slots) and the first
+    // 2 x 256 chunks of the dO tile, the 256 V-role threads the remaining 2392 chunks (10 slots)
+    static constexpr int NSQ = QCH / 256, NSK = 9, OCK = (NSK - NSQ) * 256, NSV = (OCH - OCK + 255) / 256;
 };
-static_assert(BwdBf::QCH % 256 == 0 && BwdBf::NSV == 7, "staging plan");
+static_assert(BwdBf::QCH % 256 == 0 && BwdBf::NSV == 10, "staging plan");
 static_assert(BwdBf::total <= 160 * 1024, "LDS plan");
-static_assert(BwdBf::TO % 16 == 0 && BwdBf::oK % 16 == 0 && BwdBf::oS % 16 == 0 && BwdBf::oXP % 16 == 0, "16-byte aligned regions");
+static_assert(BwdBf::TO % 16 == 0 && BwdBf::oS % 16 == 0 && BwdBf::oXP % 16 == 0, "16-byte aligned regions");
 
 __device__ __forceinline__ s16x4 lds_tr(const unsigned char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((GZ_LDS s16x4*)p);
@@ -173,43 +171,6 @@ struct BbCtx {
     bool tok_ok;
 };
 
-// dQ[l, e] += sum_tok dS[l, tok] K[tok, e] of the step whose dS image is complete: wave wv < 7 owns e tile wv of both
-// label tiles; both operands by transposed reads, k = 64 tokens
-__device__ __forceinline__ void bb_dq_product(const AttnBwdBfArgs& a, const BbCtx& c, int lt) {
-    using T = BwdBf;
-    if (c.wv >= T::NET || (BB_ABL & 2)) return;
-    const unsigned char* ktr = c.sm + T::oK + (4 * c.g + c.trq) * T::RK + 8 * c.trp + 32 * c.wv;  // rows 32ks + 16h + 4g + q, e tile wv
-    const unsigned char* str = c.sm + T::oS + (4 * c.g + c.trq) * T::RS + 8 * c.trp;
-    f32x4 q2[2];
-    q2[0] = q2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < BB_TOK / 32; ++ks) {
-        bf16x8 Bf[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            Bf[p] = join8(lds_tr(ktr + p * T::PLK + (32 * ks) * T::RK), lds_tr(ktr + p * T::PLK + (32 * ks + 16) * T::RK));
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            bf16x8 A[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                A[p] = join8(lds_tr(str + p * T::PLS + (32 * ks) * T::RS + 32 * u),
-                             lds_tr(str + p * T::PLS + (32 * ks + 16) * T::RS + 32 * u));
-            q2[u] = mfma_x6(A, Bf, q2[u]);
-        }
-    }
-    // The tile (column e = 16 wv + n, rows 16u + 4g + r) leaves as PLAIN stores into this (note, token tile)'s slab, 256
-    // contiguous bytes per instruction; attn_bwd_dq_reduce_kernel adds the slabs.  (As float atomics the 2.5 GB of partial
-    // tiles of a 64-token tiling ran into the chip's atomic rate, 1.3 TB/s, and they forced every workgroup to start its
-    // sweep at another tile, which took the tile reads out of L2.)  Streamed: they must not evict the tile images from L2.
-    float* sl = a.slab + ((((long long)(c.b * c.nTT + c.tt) * a.nLT + lt) * T::NET + c.wv) * 8) * 64 + c.lane;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (!(BB_ABL & 1)) __builtin_nontemporal_store(q2[u][r], sl + (4 * u + r) * 64);
-}
-
 // epilogue of either role: accumulator tiles (column 16j + n, token rows 4g + r) -> float atomics
 template <int NTILE>
 __device__ __forceinline__ void bb_flush(const f32x4 (&acc)[NTILE], float* gp, int W, const BbCtx& c, int Tp) {
@@ -242,13 +203,63 @@ __device__ __forceinline__ void bb_role_k(const AttnBwdBfArgs& a, const BbCtx& c
             float v[8];
             load8(krow, 32 * ks + 8 * g, a.E, c.tok_ok, vec, v);
             split3_x8(v, breg[ks]);
-            if (4 * ks + g < T::RK / 16) {  // the image holds e < 112 only
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<bf16x8*>(sm + T::oK + p * T::PLK + (c.tg * 16 + n) * T::RK + 16 * (4 * ks + g)) = breg[ks][p];
-            }
         }
     }
+    // dQ[l, e] += sum_tok dS[l, tok] K[tok, e] (k = the workgroup's 64 tokens): K-role wave tg owns the column tiles
+    // e in [16 tg, 16 tg + 16) and [16 (tg + 4), ..) of both label tiles.  Its B fragments never change over the sweep:
+    // element j of k step ks <-> token 32 ks + 16 (j >> 2) + 4 g + (j & 3) (the order the transposed reads of the dS
+    // image deliver), column e = 16 jt + n -- held in registers, read once from the fp32 keys.
+    bf16x8 kq[2][BB_TOK / 32][3];
+    {
+        const float* kb = a.PX + ((long long)c.b * a.Tp + (long long)c.tt * BB_TOK) * a.E;
+        const int trows = a.Tp - c.tt * BB_TOK;  // valid token rows of this tile
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ks = 0; ks < BB_TOK / 32; ++ks) {
+                const int e = 16 * (c.tg + 4 * jj) + n;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3);
+                    v[j] = kb[(long long)min(t, trows - 1) * a.E + min(e, a.E - 1)] * ((t < trows && e < a.E) ? 1.f : 0.f);
+                }
+                split3_x8(v, kq[jj][ks]);
+            }
+    }
+    const bool two = c.tg + 4 < NET;  // wave-uniform
+    f32x4 q2[2][2];                   // [column tile][label tile]
+    const unsigned char* str = sm + T::oS + (4 * g + c.trq) * T::RS + 8 * c.trp;
+    auto dq_half = [&](int buf, int ks) {  // one k step (32 tokens) of the product of the step whose dS image is `buf`
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            bf16x8 A[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                A[p] = join8(lds_tr(str + buf * 3 * T::PLS + p * T::PLS + (32 * ks) * T::RS + 32 * u),
+                             lds_tr(str + buf * 3 * T::PLS + p * T::PLS + (32 * ks + 16) * T::RS + 32 * u));
+            q2[0][u] = mfma_x6(A, kq[0][ks], q2[0][u]);
+            if (two) q2[1][u] = mfma_x6(A, kq[1][ks], q2[1][u]);
+        }
+    };
+    // The tiles (column e = 16 jt + n, rows 16u + 4g + r) leave as PLAIN streamed stores into this (note, token tile)'s slab,
+    // 256 contiguous bytes per instruction; attn_bwd_dq_reduce_kernel adds the slabs.
+    auto dq_store = [&](int lt) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (jj == 1 && !two) continue;
+            float* sl = a.slab + ((((long long)(c.b * c.nTT + c.tt) * a.nLT + lt) * NET + c.tg + 4 * jj) * 8) * 64 + c.lane;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (!(BB_ABL & 1)) __builtin_nontemporal_store(q2[jj][u][r], sl + (4 * u + r) * 64);
+        }
+    };
+    auto dq_zero = [&]() {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) q2[jj][0] = q2[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 #pragma unroll
     for (int j = 0; j < NET; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const uint32_t tokmul = (uint32_t)c.tok * 0x85EBCA6Bu;  // gz_u32(key, tok) = mix32(key ^ tokmul)
@@ -334,6 +345,11 @@ __device__ __forceinline__ void bb_role_k(const AttnBwdBfArgs& a, const BbCtx& c
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(xpd + p * T::XPD) = pdp[p];
         }
+        // dQ of the PREVIOUS step, first k step: fills the time the V-role wave still needs for dP (84 MFMAs against S's 48)
+        if (it > 0 && !(BB_ABL & 2)) {
+            dq_zero();
+            dq_half((it - 1) & 1, 0);
+        }
         __syncthreads();  // X: both halves of every pair's exchange are in LDS
         // ================= phase 2: dS and dK[tok, e] += sum_l dS[l, tok] Q[l, e]; B fragments by transposed reads
         {
@@ -348,7 +364,7 @@ __device__ __forceinline__ void bb_role_k(const AttnBwdBfArgs& a, const BbCtx& c
             bf16x8 dsp[3];
             split3_x8(ds, dsp);
             // dS planes -> [token][label] image (labels 16u + 4g .. +3 are one 8-byte store)
-            unsigned char* sw = sm + T::oS + (c.tg * 16 + n) * T::RS + 8 * g;
+            unsigned char* sw = sm + T::oS + (it & 1) * 3 * T::PLS + (c.tg * 16 + n) * T::RS + 8 * g;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const u32x4 w = __builtin_bit_cast(u32x4, dsp[p]);
@@ -370,13 +386,23 @@ __device__ __forceinline__ void bb_role_k(const AttnBwdBfArgs& a, const BbCtx& c
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // dQ of the previous step, second k step (dV is 78 MFMAs against dK's 42), then its tiles leave
+        if (it > 0 && !(BB_ABL & 2)) {
+            dq_half((it - 1) & 1, 1);
+            dq_store(c.step_beg + it - 1);
+        }
         __syncthreads();  // B: every wave is done with tile `it`; this step's dS image is complete
         if (!(BB_ABL & 4)) {
             if (it + 1 < nsteps) commit();
             if (it + 2 < nsteps) issue(c.step_beg + it + 2);
         }
-        bb_dq_product(a, c, c.step_beg + it);
-        __syncthreads();  // A: tile it+1 is in LDS; the dS image and the exchange buffers may be rewritten
+        __syncthreads();  // A: tile it+1 is in LDS; the exchange buffers and the other dS buffer may be rewritten
+    }
+    if (nsteps > 0 && !(BB_ABL & 2)) {
+        dq_zero();
+        dq_half((nsteps - 1) & 1, 0);
+        dq_half((nsteps - 1) & 1, 1);
+        dq_store(c.step_beg + nsteps - 1);
     }
     bb_flush<NET>(acc, a.dPX + ((long long)c.b * a.Tp + c.tok0) * a.E, a.E, c, a.Tp);
 }
@@ -474,7 +500,6 @@ __device__ __forceinline__ void bb_role_v(const AttnBwdBfArgs& a, const BbCtx& c
             if (it + 1 < nsteps) commit();
             if (it + 2 < nsteps) issue(c.step_beg + it + 2);
         }
-        bb_dq_product(a, c, c.step_beg + it);
         __syncthreads();  // A
     }
     bb_flush<NFT>(acc, a.dX + ((long long)c.b * a.Tp + c.tok0) * a.F, a.F, c, a.Tp);
