@@ -58,3 +58,36 @@ __device__ __forceinline__ void mfma_x6_3acc(const bf16x8 (&a)[3], const bf16x8 
     mid = mfma_bf16(a[0], b[1], mid);
     hi = mfma_bf16(a[0], b[0], hi);
 }
+
+// The same two products with the LDS reads of a later item's planes issued BETWEEN the MFMAs (ld(p) reads plane p): a
+// wave issues in order, so reads bunched in front of an item's MFMAs are cycles in which it feeds the matrix pipe nothing.
+template <class LD>
+__device__ __forceinline__ f32x4 mfma_x6_il(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c, LD&& ld) {
+    c = mfma_bf16(a[2], b[0], c);
+    ld(0);
+    __builtin_amdgcn_sched_barrier(0);
+    c = mfma_bf16(a[0], b[2], c);
+    c = mfma_bf16(a[1], b[1], c);
+    ld(1);
+    __builtin_amdgcn_sched_barrier(0);
+    c = mfma_bf16(a[1], b[0], c);
+    c = mfma_bf16(a[0], b[1], c);
+    ld(2);
+    __builtin_amdgcn_sched_barrier(0);
+    return mfma_bf16(a[0], b[0], c);
+}
+template <class LD>
+__device__ __forceinline__ void mfma_x6_3acc_il(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4& hi, f32x4& mid, f32x4& lo, LD&& ld) {
+    lo = mfma_bf16(a[2], b[0], lo);
+    ld(0);
+    __builtin_amdgcn_sched_barrier(0);
+    mid = mfma_bf16(a[1], b[0], mid);
+    hi = mfma_bf16(a[0], b[0], hi);
+    ld(1);
+    __builtin_amdgcn_sched_barrier(0);
+    lo = mfma_bf16(a[0], b[2], lo);
+    mid = mfma_bf16(a[0], b[1], mid);
+    ld(2);
+    __builtin_amdgcn_sched_barrier(0);
+    lo = mfma_bf16(a[1], b[1], lo);
+}
