@@ -524,6 +524,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    dt_issue = time.perf_counter() - t0  # host time to ISSUE the timed steps (nothing in a step synchronises)
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -567,6 +568,9 @@ def main():
                                              'achieved': step_flops(d, B) / world / (dt / args.steps) / 1e12,
                                              'frac': step_flops(d, B) / world / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}},
         'loss': float(loss.detach()),
+        # Boundary overhead: Python + ctypes + ATen time per step on the issuing thread.  While it is
+        # below ms_per_step the host runs ahead of the GPU and the boundary costs nothing; equal to it means host-bound.
+        'host_issue_ms_per_step': dt_issue / args.steps * 1e3,
     }
     if dist_on:
         out['comm'] = {'world_size_seen_by_rccl': dist.get_world_size(), 'backend': dist.get_backend(),
