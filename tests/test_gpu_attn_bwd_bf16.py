@@ -27,7 +27,8 @@ def _ops(bf):
     return ops
 
 
-@pytest.mark.parametrize('B,Tp,E,F,L', BF_SHAPES + [(2, 130, 112, 208, 65), (1, 64, 100, 200, 32)])
+@pytest.mark.parametrize('B,Tp,E,F,L', BF_SHAPES + [(2, 130, 112, 208, 65), (1, 64, 100, 200, 32),
+                                        (8, 200, 100, 200, 70), (16, 70, 36, 52, 100)])  # B % 8 == 0: the XCD-aware workgroup order
 @pytest.mark.parametrize('p', [0.0, 0.2])
 def test_label_attention_bwd_bf16x6(ref, B, Tp, E, F, L, p):
     ops = _ops(True)
