@@ -216,8 +216,7 @@ __device__ __forceinline__ void bb_flush(const f32x4 (&acc)[NTILE], float* gp, i
 }
 
 // ---- K role: K planes (B fragments of S; element j of k step ks <-> e = 32 ks + 8 g + j), S, P, dS, dK, dQ.  Brings in
-// the Q tile (LDS-DMA) and the first OCK chunks of the dO tile.  (DROP is unused here: the mask lives in the V role.)
-template <bool DROP>
+// the Q tile (LDS-DMA) and the first OCK chunks of the dO tile.  (Dropout does not appear here: the mask lives in the V role.)
 __device__ __forceinline__ void bb_role_k(const AttnBwdBfArgs& a, const BbCtx& c) {
     using T = BwdBf;
     constexpr int EKS = T::EKS, NET = T::NET;
@@ -522,9 +521,6 @@ __device__ __forceinline__ void bb_role_v(const AttnBwdBfArgs& a, const BbCtx& c
         commit();
     }
     __syncthreads();
-#ifdef BB_VPRIO
-    __builtin_amdgcn_s_setprio(BB_VPRIO);
-#endif
     BB_T_BEGIN
     for (int it = 0; it < nsteps; ++it) {
         const int lt_next = min(c.step_beg + it + 1, a.nLT - 1);
@@ -665,7 +661,7 @@ __global__ __launch_bounds__(BB_NT) void label_attn_bwd_bf16_kernel(AttnBwdBfArg
     c.nsteps = max(0, min(a.nLT, c.step_beg + steps_per) - c.step_beg);
     // the two roles run the same number of barriers per step (s_barrier counts arrivals, not program locations)
     if (c.wv >= BB_TG) bb_role_v<DROP>(a, c);
-    else bb_role_k<DROP>(a, c);
+    else bb_role_k(a, c);
 }
 
 // dQ[l, e] += sum over the (note, token tile) slabs of the partial tiles label_attn_bwd_bf16_kernel stored, in slab order
