@@ -20,6 +20,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 @pytest.fixture(scope='module')
 def ext():
     from gzsl_text_amd import torch_ext
+    torch_ext.build()  # no-op when lib/libgzsl_torch.so is newer than its sources (g++, ~15 s otherwise)
     torch_ext.load()
     return torch.ops.gzsl
 
