@@ -397,6 +397,7 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
         constexpr int STW = 132;
         float* st = lds + wave * (16 * STW);
         const int rr0 = lane >> 5, c4 = (lane & 31) * 4;
+        float dotp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // fused head: partial dot products of rows 2i + rr0
 #pragma unroll
         for (int ps = 0; ps < (16 * WTN + 127) / 128; ++ps) {
 #pragma unroll
@@ -430,9 +431,25 @@ __global__ __launch_bounds__(NTHREADS, !VEC ? 1 : (WTM == 1 ? (BK == 16 ? 3 : 2)
                         else if (g.act == GZSL_ACT_LRELU) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
                     }
                 }
+                if (g.dot_w) {  // fused head: this lane's four columns of <relu(row), dot_w[row % period]>
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(g.dot_w + (long long)(row % g.dot_period) * g.N + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dotp[r2 >> 1] += fmaxf(v[e], 0.f) * w[e];
+                    if (g.dot_no_store) continue;
+                }
                 *reinterpret_cast<f32x4*>(cp) = v;
             }
             wave_lds_fence();  // ... and the next pass overwrites them
+        }
+        if (g.dot_w) {  // a row's columns sit in the 32 lanes of one half-wave (rr0 = lane >> 5): butterfly inside it
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float s = dotp[i];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+                const int row = m0 + tile_row<A_RC, 4>(wave, 2 * i + rr0);
+                if ((lane & 31) == 0 && row < g.M) g.dot_out[row] = s;
+            }
         }
         return;
     }
@@ -749,6 +766,12 @@ extern "C" int gzsl_gemm(const GzslGemm* gp, void* stream) {
     if (g.split_k > 1) {
         if (g.k_per_split <= 0 || g.k_per_split % BK != 0) return GZSL_EINVAL;
         if ((long long)g.k_per_split * g.split_k < g.K) return GZSL_EINVAL;
+    }
+    if (g.dot_w) {  // fused head: one 64 x 208 tile row per workgroup, the vector epilogue (see the header)
+        if (!g.dot_out || g.dot_period <= 0 || g.N > 208 || (g.N & 3) || (g.ldc & 3) || g.split_k > 1 || g.accumulate ||
+            (((uintptr_t)g.C | (uintptr_t)g.bias | (uintptr_t)g.dot_w) & 15) != 0)
+            return GZSL_EINVAL;
+        return launch_cfg<1, 13>(g, st);
     }
     // few rows, plain operands: the skinny kernel (columns over workgroups, K over the waves of a workgroup)
     static const int no_skinny = env_int("GZSL_GEMM_NO_SKINNY", 0);

@@ -17,6 +17,7 @@ from .hip import ACT_NONE, ACT_RELU, ACT_TANH
 P_EMB_DROP = 0.5   # icd_modules.py:55
 P_ATTN_DROP = 0.2  # icd_modules.py:59
 EPS_DEG = 1e-7     # graph_module.py:117
+_NO_FUSED_HEAD = __import__('os').environ.get('GZSL_NO_FUSED_HEAD') == '1'  # diagnostic: output_proj and logits as two launches
 
 
 def build_csr(adj):
@@ -218,7 +219,7 @@ class BaseEngine:
             self.ops.attn_bwd(dO[c0:c1], O[c0:c1], PX, X, Q, lse[c0:c1], l_offset + c0 * L_total, L_total, seed,
                               P_ATTN_DROP if training else 0.0, dPX, dX, dQ, delta=None if delta is None else delta[c0:c1])
 
-    def head_fwd(self, P, X, PX, Q, clf, l_offset, L_total, seed, training, attn=None):
+    def head_fwd(self, P, X, PX, Q, clf, l_offset, L_total, seed, training, attn=None, need_direct=True):
         """icd_modules.py:137-142,159,177-182 for the label rows [l_offset, l_offset + len(Q)).  attn = (O, lse) when
         the caller has already run the attention (note block by note block)."""
         ops = self.ops
@@ -227,6 +228,13 @@ class BaseEngine:
         else:
             O, lse = attn
         B, L, F_ = O.shape
+        # output_proj + relu + per-label dot in one launch where the GEMM's fused epilogue has a form for it; with
+        # need_direct=False (forward-only scoring) `direct` [B,L,D] is never written
+        fused = None if _NO_FUSED_HEAD else getattr(ops, 'linear_logits', None)
+        out = fused(O.view(B * L, F_), P['output_proj.weight'], P['output_proj.bias'], clf, need_direct) if fused else None
+        if out is not None:
+            direct, logits = out
+            return O, lse, (None if direct is None else direct.view(B, L, -1)), logits.view(B, L)
         direct = ops.linear(O.view(B * L, F_), P['output_proj.weight'], P['output_proj.bias']).view(B, L, -1)
         logits = ops.logits_fwd(direct, clf)
         return O, lse, direct, logits

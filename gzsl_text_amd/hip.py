@@ -27,7 +27,8 @@ class GzslGemm(ctypes.Structure):
                 ('a_shift', c_int), ('a_span', ctypes.c_uint), ('k_inner', c_int), ('a_kbs', c_ll),
                 ('b_sk', c_int), ('b_sn', c_int), ('b_kbs', c_ll),
                 ('ldc', c_int), ('act', c_int), ('accumulate', c_int), ('alpha', c_float),
-                ('split_k', c_int), ('k_per_split', c_int), ('slab_stride', c_ll)]
+                ('split_k', c_int), ('k_per_split', c_int), ('slab_stride', c_ll),
+                ('dot_w', c_void_p), ('dot_out', c_void_p), ('dot_period', c_int), ('dot_no_store', c_int)]
 
 
 # name -> argtypes (every entry point include/gzsl_hip.h declares; tests check the export list against the header)

@@ -101,7 +101,7 @@ class _BaseModelFn(torch.autograd.Function):
             beside.join()
         Q = avg[l0:l1]
         clf = graph[l0:l1]
-        O, lse, direct, logits_l = eng.head_fwd(P, X, PX, Q, clf, l0, L, seed, training, attn=attn)
+        O, lse, direct, logits_l = eng.head_fwd(P, X, PX, Q, clf, l0, L, seed, training, attn=attn, need_direct=need_grad)
         margin = mod.class_margin
         y_l = y if (l0 == 0 and l1 == y.shape[1]) else y[:, l0:l1]
         y_l = y_l.contiguous().to(torch.float32)
@@ -417,7 +417,7 @@ class _GanModelFn(torch.autograd.Function):
                 margin = margin[l0:l1].contiguous()
         # a label subset keeps its GLOBAL dropout coordinates only when it is the identity; a gathered subset is a
         # different attention problem in the reference too (fresh torch dropout mask), so rows are numbered locally
-        O, lse, direct, logits = eng.head_fwd(P, X, PX, Q, clf, l0, Lp, seed, training)
+        O, lse, direct, logits = eng.head_fwd(P, X, PX, Q, clf, l0, Lp, seed, training, need_direct=need_grad)
         loss, dlogits, _ = eng.ops.ldam_bce(logits, y.contiguous().to(torch.float32), margin, mod.C, 1.0 / B,
                                             need_grad=need_grad)
         if sh is not None:

@@ -146,6 +146,37 @@ class HipOps:
         """nn.Linear: x[M,K] @ W[N,K]^T + b."""
         return self.mm(x, W.t(), out=out, bias=b, act=act, accumulate=accumulate)
 
+    def linear_logits(self, x, W, b, clf, need_direct=True):
+        """The classifier head in ONE launch (icd_modules.py:159 + 177-182; the GEMM's fused row-dot epilogue, SURVEY 2.2
+        K8/K9): direct = x @ W^T + b [M,D] and logits[m] = <relu(direct[m]), clf[m % L]> [M], rows m = b*L + l.
+        need_direct=False (forward-only scoring) does not write `direct` at all.  Returns (direct | None, logits), or
+        None where the epilogue has no form (D > 208 or D % 4: the caller runs linear + logits_fwd)."""
+        _check_f32(x, W, b, clf)
+        M, K = x.shape
+        D = W.shape[0]
+        L = clf.shape[0]
+        if D > 208 or D % 4 or clf.shape[1] != D or not clf.is_contiguous() or M % L:
+            return None
+        if any(t.data_ptr() % 16 for t in (clf, b)):
+            return None
+        direct = torch.empty((M, D), dtype=torch.float32, device=x.device) if need_direct else None
+        logits = torch.empty(M, dtype=torch.float32, device=x.device)
+        Bt = W.t()
+        g = GzslGemm()
+        g.A, g.B = dptr(x), dptr(Bt)
+        g.a_mb, g.a_mbs, g.a_sm, g.a_sk, g.a_shift, g.a_span = max(M, 1), 0, x.stride(0), x.stride(1), 0, INT_MAX
+        g.k_inner, g.a_kbs, g.b_kbs = max(K, 1), 0, 0
+        g.b_sk, g.b_sn = Bt.stride(0), Bt.stride(1)
+        g.alpha = 1.0
+        g.M, g.N, g.K = M, D, K
+        # (without a store the C pointer is never dereferenced; it still has to be 16-byte aligned and non-null)
+        g.C, g.ldc = dptr(direct if need_direct else logits), D
+        g.bias, g.act, g.accumulate = ptr(b), ACT_NONE, 0
+        g.split_k, g.k_per_split, g.slab_stride = 1, 0, 0
+        g.dot_w, g.dot_out, g.dot_period, g.dot_no_store = dptr(clf), dptr(logits), L, 0 if need_direct else 1
+        call('gzsl_gemm', g)
+        return direct, logits
+
     def colsum(self, x2d, out=None):
         M, N = x2d.shape
         assert x2d.stride(1) == 1

@@ -48,6 +48,16 @@ typedef struct GzslGemm {
     int split_k;           /* > 1: blockIdx.z owns k_per_split of K and writes alpha*partial to C + z*slab_stride */
     int k_per_split;       /* multiple of 32 */
     long long slab_stride; /* elements */
+    /* Optional fused classifier head (icd_modules.py:159 + 177-182): with dot_w set, every output row
+     * m ALSO yields dot_out[m] = sum_n relu(C[m,n]) * dot_w[(m % dot_period) * N + n] from the tile in registers
+     * (C = the epilogue's value: alpha*A.B + bias, act applied), i.e. logits[b,l] = <relu(direct[b,l,:]), clf[l,:]>
+     * without a second pass over `direct`; dot_no_store = 1 additionally skips writing C (forward-only scoring never
+     * reads it).  Needs one tile across N (N <= 208), N % 4 == 0, ldc % 4 == 0, 16-byte aligned C / bias / dot_w,
+     * no split-K, no accumulate (else GZSL_EINVAL). */
+    const float* dot_w;
+    float* dot_out;
+    int dot_period;
+    int dot_no_store;
 } GzslGemm;
 int gzsl_gemm(const GzslGemm* g, void* stream);
 /* out = act(sum_z slab[z] + bias) (+ out); unpack_k > 0 scatters a [(j*E+e), f] slab into conv weight layout [F,E,k] */

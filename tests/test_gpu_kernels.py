@@ -657,3 +657,30 @@ def test_conv_full_size_linearity(ops):
     # one output against a direct dot product
     want = float((e1[3, 77:77 + k].t() * W[5]).sum() + b[5])
     assert abs(float(y1[3, 77, 5]) - want) < 1e-4 * abs(want)
+
+
+@pytest.mark.parametrize('B,L,F,D', [(2, 37, 52, 36), (3, 70, 200, 200), (1, 5, 24, 16), (2, 129, 200, 208), (16, 64, 100, 4)])
+@pytest.mark.parametrize('need_direct', [True, False])
+def test_fused_output_proj_and_label_logits(ops, B, L, F, D, need_direct):
+    """gzsl_gemm's fused head epilogue (icd_modules.py:159 + 177-182 in one launch) against the two-launch form and the
+    torch-fp32 statement; need_direct=False must not need (or touch) a `direct` buffer."""
+    rs = np.random.RandomState(B * 100 + L + D)
+    O, Wo, bo, clf = g(rnd(rs, B * L, F)), g(rnd(rs, D, F, scale=0.2)), g(rnd(rs, D, scale=0.1)), g(rnd(rs, L, D))
+    out = ops.linear_logits(O, Wo, bo, clf, need_direct=need_direct)
+    assert out is not None
+    direct, logits = out
+    want_direct = O.double() @ Wo.double().t() + bo.double()
+    want = (torch.relu(want_direct).view(B, L, D) * clf.double()[None]).sum(2).reshape(-1)
+    close(logits, want, 1e-5, 2e-5 * np.sqrt(D), 'fused logits')
+    if need_direct:
+        close(direct, want_direct, 1e-5, 1e-5 * np.sqrt(F), 'direct')
+        two = ops.logits_fwd(ops.linear(O, Wo, bo).view(B, L, D), clf).reshape(-1)
+        close(logits, two, 1e-5, 1e-5 * np.sqrt(D), 'fused vs two launches')
+    else:
+        assert direct is None
+
+
+def test_fused_head_declines_shapes_without_a_form(ops):
+    O, Wo, bo = torch.zeros(6, 8, device=DEV), torch.zeros(210, 8, device=DEV), torch.zeros(210, device=DEV)
+    assert ops.linear_logits(O, Wo, bo, torch.zeros(3, 210, device=DEV)) is None        # wider than one tile
+    assert ops.linear_logits(O, Wo[:6], bo[:6], torch.zeros(3, 6, device=DEV)) is None  # D % 4
